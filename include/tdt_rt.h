@@ -1,0 +1,149 @@
+/*
+ * tdt_rt.h — C ABI of libtdtrt.so, the MI355X (gfx950) drop-in for the per-pixel voxel path
+ * trace of Avokadoen/tdt4230_project_raytracing.
+ *
+ * The reference has no FFI layer: its boundary is the `src/renderer` GL-wrapper API that
+ * main.rs / camera.rs / octree.rs call on the thread that owns the GL context.  Every entry
+ * point below replaces one of those calls one-for-one (cited as file:line of the reference);
+ * a Rust maintainer binds them with the `extern "C"` block shown in INTEGRATION.md.
+ *
+ * Conventions (the GL contract, kept):
+ *   - context-affine, no internal locking: call from one thread per context;
+ *   - host pointers are borrowed for the duration of the call only; uploads COPY (glBufferData);
+ *   - every call returns an int: 0 = TDT_OK, otherwise a TDT_ERR_* code (never aborts); the
+ *     message for the last error of a context is available from tdt_last_error();
+ *   - handles are owned by their context and die with it;
+ *   - all dispatches are asynchronous on the context's HIP stream; tdt_finish() is glFinish().
+ * There is NO CPU fallback: without a usable HIP device tdt_ctx_create fails with
+ * TDT_ERR_NO_DEVICE and nothing else can be called.
+ */
+#ifndef TDT_RT_H
+#define TDT_RT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tdt_ctx tdt_ctx;         /* the GL context            main.rs:58-61,108-112 */
+typedef struct tdt_compute tdt_compute; /* renderer::ComputeShader   compute_shader.rs:10-13 */
+typedef struct tdt_buffer tdt_buffer;   /* renderer::vbo::VertexBufferObject   vbo.rs:9-13 */
+typedef struct tdt_image tdt_image;     /* renderer::texture::Texture          texture.rs:7-14 */
+
+enum {
+  TDT_OK = 0,
+  TDT_ERR_NO_DEVICE = 1,          /* no HIP device / HIP runtime failure at context creation  */
+  TDT_ERR_HIP = 2,                /* a HIP call failed (check_for_gl_error analogue, mod.rs:62-68) */
+  TDT_ERR_INVALID_ENUM = 0x0500,  /* = GL_INVALID_ENUM,      mod.rs:47 */
+  TDT_ERR_INVALID_VALUE = 0x0501, /* = GL_INVALID_VALUE,     mod.rs:48 */
+  TDT_ERR_INVALID_OPERATION = 0x0502, /* = GL_INVALID_OPERATION, mod.rs:49 */
+  TDT_ERR_VARIABLE_NOT_FOUND = 3, /* InitializeErr::VariableNotFound, program.rs:144-165, mod.rs:31 */
+  TDT_ERR_INCOMPLETE = 4          /* dispatch with a required binding / uniform missing */
+};
+
+/* kinds for tdt_compute_create (the two compute programs the reference links) */
+enum {
+  TDT_PROGRAM_RAYTRACER = 0,      /* assets/shaders/raytracer.comp */
+  TDT_PROGRAM_OCTREE_UPDATE = 1   /* assets/shaders/octree_update.comp — not built: TDT_ERR_INVALID_ENUM */
+};
+/* targets for tdt_bind_buffer_base (values are the GL enums the reference passes) */
+enum {
+  TDT_SHADER_STORAGE_BUFFER = 0x90D2, /* main.rs:352,383,408,430,448; octree.rs:67,98,144 */
+  TDT_ATOMIC_COUNTER_BUFFER = 0x92C0  /* octree.rs:115 (accepted, unused by the trace) */
+};
+/* SSBO slots read by raytracer.comp (binding = N in the shader) */
+enum {
+  TDT_SLOT_CELLS = 0,        /* Node{uint value; uint type}[]          raytracer.comp:180-182 */
+  TDT_SLOT_MATERIALS = 1,    /* {int type, attribute_index, albedo_index}[]   :189-196 */
+  TDT_SLOT_ALBEDOS = 2,      /* {float x,y,z}[]                                :203-210 */
+  TDT_SLOT_METAL = 3,        /* {float fuzz}[]                                 :214-219 */
+  TDT_SLOT_DIELECTRIC = 4,   /* {float ir}[]                                   :222-227 */
+  TDT_SLOT_DELTA = 5,        /* octree_update.comp only; accepted, ignored               */
+  TDT_SLOT_OCTREE_FLOATS = 6,/* {vec4 min_point; float scale, inv_scale, inv_cell_count} :150-158 */
+  TDT_SLOT_OCTREE_INTS = 7   /* {int max_depth, max_iter, cell_count}          :159-166 */
+};
+
+/* ---- context ------------------------------------------------------------------------- */
+/* Replaces GL context creation + make_current (main.rs:58-61,108-112).  `stream` is a
+ * hipStream_t to launch on (NULL: the context creates its own non-blocking stream). */
+int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out);
+void tdt_ctx_destroy(tdt_ctx *ctx);
+/* glFinish: block until every dispatch of this context has completed. */
+int tdt_finish(tdt_ctx *ctx);
+/* message of the most recent error on this context ("" if none); ctx may be NULL for
+ * errors of tdt_ctx_create itself */
+const char *tdt_last_error(const tdt_ctx *ctx);
+/* InitializeErr's Display (mod.rs:44-59) for a code */
+const char *tdt_strerror(int code);
+
+/* ---- programs / uniforms --------------------------------------------------------------- */
+/* Shader::from_resources + Program::from_shaders + ComputeShader::new
+ * (shader.rs:26, program.rs:101, compute_shader.rs:15-26; called main.rs:156-160). */
+int tdt_compute_create(tdt_ctx *ctx, int kind, tdt_compute **out);
+void tdt_compute_destroy(tdt_compute *c);          /* Program::drop, program.rs:169 */
+/* the COMPUTE_WORK_GROUP_SIZE query of compute_shader.rs:18: {32,32,1} */
+int tdt_compute_group_size(const tdt_compute *c, int out[3]);
+/* Program::set_i32 / set_f32 / set_vector3_f32 / set_vector3_i32 (program.rs:35-83): uniform
+ * addressed by its GLSL name, e.g. "camera.image_width"; unknown name or wrong type ->
+ * TDT_ERR_VARIABLE_NOT_FOUND.  Takes effect for the next dispatch. */
+int tdt_set_i32(tdt_compute *c, const char *name, int32_t value);
+int tdt_set_f32(tdt_compute *c, const char *name, float value);
+int tdt_set_vec3f(tdt_compute *c, const char *name, float x, float y, float z);
+int tdt_set_vec3i(tdt_compute *c, const char *name, int32_t x, int32_t y, int32_t z);
+
+/* ---- buffers ---------------------------------------------------------------------------- */
+/* VertexBufferObject::new::<T>(Vec<T>, ..) = glGenBuffers + glBufferData (vbo.rs:32-55):
+ * copies `bytes` bytes to device memory. */
+int tdt_buffer_create(tdt_ctx *ctx, const void *data, size_t bytes, tdt_buffer **out);
+void tdt_buffer_destroy(tdt_buffer *b);
+/* gl::BindBufferBase(target, slot, id) as called by main.rs:352-448 and octree.rs:67-144 */
+int tdt_bind_buffer_base(tdt_ctx *ctx, int target, unsigned slot, tdt_buffer *b);
+/* gl::BufferSubData (octree.rs:174); only meaningful for the edit path (next row §8f-2) */
+int tdt_buffer_sub_data(tdt_buffer *b, size_t offset, size_t bytes, const void *data);
+
+/* ---- image ------------------------------------------------------------------------------ */
+/* Texture::new_2d(TEXTURE0, 0, RGBA32F, RGBA, w, h) (texture.rs:47-75, camera.rs:158-165):
+ * W*H*4 floats in device memory, row 0 = bottom scan line, zero-filled (the reference leaves
+ * it undefined). */
+int tdt_image_create_rgba32f(tdt_ctx *ctx, int width, int height, tdt_image **out);
+/* Same, but over device memory the caller owns (e.g. a torch tensor's data_ptr) — used by
+ * the multi-GPU harness so the per-rank tile can be handed to RCCL without a copy. */
+int tdt_image_wrap_device(tdt_ctx *ctx, void *device_ptr, int width, int height, tdt_image **out);
+void tdt_image_destroy(tdt_image *img);
+/* glBindImageTexture(unit, ..) of texture.rs:71: only unit 0 exists in raytracer.comp:4 */
+int tdt_bind_image(tdt_ctx *ctx, unsigned unit, tdt_image *img);
+int tdt_image_width(const tdt_image *img);
+int tdt_image_height(const tdt_image *img);
+void *tdt_image_device_ptr(const tdt_image *img);
+/* NEW (the reference never reads back; quad.frag samples the texture): finishes the stream and
+ * copies W*H*4 floats to dst */
+int tdt_image_read(tdt_image *img, float *dst);
+
+/* ---- dispatch --------------------------------------------------------------------------- */
+/* ComputeShader::dispatch_compute(width, height, depth) (compute_shader.rs:28-38; called with
+ * (W+1, H+1, 1) at main.rs:579): work-group counts are max(dim / 32, 1) by integer floor
+ * division, the shader has no bounds check, image stores outside the image are dropped;
+ * followed by the image-access barrier (= stream order here).  Asynchronous. */
+int tdt_dispatch_compute(tdt_compute *c, int width, int height, int depth);
+
+/* ---- extensions with no reference counterpart (documented in DESIGN.md) ------------------ */
+/* Tile partition for one-process-per-GPU rendering: subsequent dispatches of `c` trace only
+ * the 32-pixel work-group rows r with r % world == rank.  Default (0,1). */
+int tdt_set_partition(tdt_compute *c, int rank, int world);
+/* Progressive form of the sample loop: adds samples [spp_begin, spp_begin+spp_count) of every
+ * covered pixel, in sample order, to the bound image's rgb running sums (and keeps the
+ * shader's loop-carried temporaries in `carry`, W*H*16 floats of device memory, may be NULL
+ * on the first pass only if spp_begin == 0 and no further pass follows). */
+int tdt_dispatch_accumulate(tdt_compute *c, int width, int height, int depth, int spp_begin, int spp_count,
+                            void *carry_device_ptr);
+/* image = clamp(sqrt(sum / total_spp), 0, 1), alpha = 1: raytracer.comp:249-251 */
+int tdt_dispatch_resolve(tdt_compute *c, int width, int height, int depth, int total_spp);
+/* number of pixels a dispatch of (width,height,depth) writes under the current partition */
+int64_t tdt_covered_pixels(const tdt_compute *c, int width, int height, int depth);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TDT_RT_H */

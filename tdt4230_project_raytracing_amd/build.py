@@ -1,0 +1,53 @@
+"""Build recipes for the two in-tree shared libraries (explicit compiler invocations, outputs
+stay in-tree so they travel to the GPU box with the snapshot)."""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+
+HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+# -ffp-contract=off and IEEE divide/sqrt are PARITY flags, not tuning knobs: the reference's
+# arithmetic is unfused and correctly rounded (DESIGN.md "Numerics").
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+             "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wextra"]
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-ffp-contract=off"]
+
+
+def _newer(out, srcs):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(s) > t for s in srcs)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    return r.stdout + r.stderr
+
+
+def build_host(force=False):
+    out = os.path.join(_HERE, "libtdthost.so")
+    srcs = [os.path.join(CSRC, "host_scene.cpp"), os.path.join(INCLUDE, "tdt_host.h")]
+    if force or _newer(out, srcs):
+        _run(["g++"] + HOST_FLAGS + ["-I", INCLUDE, srcs[0], "-o", out])
+    return out
+
+
+def build_device(force=False, extra_flags=()):
+    out = os.path.join(_HERE, "libtdtrt.so")
+    srcs = [os.path.join(CSRC, f) for f in ("tdt_rt.hip", "trace_device.hpp", "trace_params.h")] + \
+           [os.path.join(INCLUDE, "tdt_rt.h")]
+    if force or _newer(out, srcs):
+        _run([HIPCC] + HIP_FLAGS + list(extra_flags) + ["-I", INCLUDE, "-I", CSRC, srcs[0], "-o", out])
+    return out
+
+
+def build_all(force=False):
+    return build_host(force), build_device(force)

@@ -1,0 +1,526 @@
+// libtdtrt.so — the C ABI of include/tdt_rt.h over hand-written gfx950 kernels.
+//
+// Host part: a one-for-one stand-in for the reference's `src/renderer` GL wrappers (context,
+// buffer upload + binding, RGBA32F image, uniform-by-name, dispatch_compute); device part: the
+// per-pixel trace of assets/shaders/raytracer.comp.  There is no CPU path in this library.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "tdt_rt.h"
+#include "trace_device.hpp"
+#include "trace_params.h"
+
+// ============================================================================ kernels ======
+namespace tdt {
+
+// Pixel owned by this thread.  One wave64 = one 8x8 screen tile; a 256-thread block = a
+// 16x16 pixel quad of tiles.  blockIdx.y walks the 16-pixel half-rows of the 32-pixel
+// work-group rows this rank owns (group row = rank + k*world: SURVEY §8e).
+TDT_DEV bool pixel_of_thread(const TraceParams &P, int &x, int &y, int &img_row) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int k = blockIdx.y >> 1, half = blockIdx.y & 1;
+  const int group_row = P.part_rank + k * P.part_world;
+  x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+  const int in_group = half * 16 + (wave >> 1) * 8 + (lane >> 3);
+  y = group_row * 32 + in_group;
+  img_row = P.compact ? (k * 32 + in_group) : y;
+  return x < P.cover_w && y < P.cover_h && img_row < P.image_rows;
+}
+
+// mode 0: the whole of main() rc:234-252.  mode 1: only the sample loop, adding to running sums.
+template <int MODE>
+__global__ __launch_bounds__(256) void trace_kernel(const TraceParams P) {
+  int x, y, row;
+  if (!pixel_of_thread(P, x, y, row)) return;
+  const size_t pix = (size_t)row * (size_t)P.image_width + (size_t)x;
+  float4 *dst = reinterpret_cast<float4 *>(P.image) + pix;
+
+  Carry pc;
+  pc.root = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}; pc.leaf = pc.root; pc.root_t = 0.f;
+  float sr = 0.f, sg = 0.f, sb = 0.f;
+  if (MODE == 1) {
+    float4 acc = *dst;
+    sr = acc.x; sg = acc.y; sb = acc.z;
+    if (P.carry) {
+      const float4 *c = reinterpret_cast<const float4 *>(P.carry) + pix * 4;
+      float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+      pc.root = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z != 0.f}; pc.root_t = c1.w;
+      pc.leaf = {c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z != 0.f};
+    }
+  }
+  const int s_end = P.spp_begin + P.spp_count;
+  for (int s = P.spp_begin; s < s_end; s++) {
+    Ray r = primary_ray(P, x, y, s);
+    float cr, cg, cb;
+    ray_color(P, r, pc, cr, cg, cb);
+    sr = sr + cr; sg = sg + cg; sb = sb + cb;
+  }
+  if (MODE == 1) {
+    *dst = make_float4(sr, sg, sb, 0.f);
+    if (P.carry) {
+      float4 *c = reinterpret_cast<float4 *>(P.carry) + pix * 4;
+      c[0] = make_float4(pc.root.nx, pc.root.ny, pc.root.nz, pc.root.px);
+      c[1] = make_float4(pc.root.py, pc.root.pz, pc.root.ff ? 1.f : 0.f, pc.root_t);
+      c[2] = make_float4(pc.leaf.nx, pc.leaf.ny, pc.leaf.nz, pc.leaf.px);
+      c[3] = make_float4(pc.leaf.py, pc.leaf.pz, pc.leaf.ff ? 1.f : 0.f, 0.f);
+    }
+  } else {
+    const float n = (float)P.samples_per_pixel;   // rc:249-251
+    float4 o;
+    o.x = f_min(f_max(__builtin_sqrtf(sr / n), 0.f), 1.f);
+    o.y = f_min(f_max(__builtin_sqrtf(sg / n), 0.f), 1.f);
+    o.z = f_min(f_max(__builtin_sqrtf(sb / n), 0.f), 1.f);
+    o.w = 1.0f;
+    *dst = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void resolve_kernel(const TraceParams P) {
+  int x, y, row;
+  if (!pixel_of_thread(P, x, y, row)) return;
+  float4 *dst = reinterpret_cast<float4 *>(P.image) + ((size_t)row * (size_t)P.image_width + (size_t)x);
+  float4 a = *dst;
+  const float n = (float)P.total_spp;
+  float4 o;
+  o.x = f_min(f_max(__builtin_sqrtf(a.x / n), 0.f), 1.f);
+  o.y = f_min(f_max(__builtin_sqrtf(a.y / n), 0.f), 1.f);
+  o.z = f_min(f_max(__builtin_sqrtf(a.z / n), 0.f), 1.f);
+  o.w = 1.0f;
+  *dst = o;
+}
+
+}  // namespace tdt
+
+// ============================================================================ host ABI =====
+namespace {
+thread_local std::string g_create_err;
+constexpr int kNumSlots = 8;
+}
+
+struct tdt_buffer {
+  tdt_ctx *ctx;
+  void *dev;
+  size_t bytes;
+  unsigned char shadow[64];   // first bytes, host side: the octree uniform blocks are read from here
+};
+
+struct tdt_image {
+  tdt_ctx *ctx;
+  float *dev;
+  int w, h;
+  bool owned;
+};
+
+struct tdt_ctx {
+  int device;
+  hipStream_t stream;
+  bool own_stream;
+  std::string err;
+  tdt_buffer *ssbo[kNumSlots];
+  tdt_buffer *atomic0;
+  tdt_image *image0;
+  std::vector<tdt_buffer *> buffers;
+  std::vector<tdt_image *> images;
+  std::vector<tdt_compute *> computes;
+};
+
+struct tdt_compute {
+  tdt_ctx *ctx;
+  int kind;
+  // `uniform Camera camera` raytracer.comp:133-146; GL initialises uniforms to 0
+  int32_t image_width, image_height, samples_per_pixel, max_bounce;
+  float horizontal[3], vertical[3], lower_left_corner[3], origin[3];
+  int part_rank, part_world;
+};
+
+namespace {
+
+int fail(tdt_ctx *ctx, int code, const std::string &msg) {
+  if (ctx) ctx->err = msg; else g_create_err = msg;
+  return code;
+}
+int hip_fail(tdt_ctx *ctx, hipError_t e, const char *what) {
+  return fail(ctx, TDT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define TDT_HIP(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail((ctx), e_, #call); } while (0)
+
+template <class T> void erase_from(std::vector<T *> &v, T *p) {
+  for (size_t i = 0; i < v.size(); i++) if (v[i] == p) { v.erase(v.begin() + i); return; }
+}
+
+// ComputeShader::dispatch_compute's group arithmetic (compute_shader.rs:30-32) and what it covers
+struct Cover { int groups_x, groups_y, cover_w, cover_h; };
+Cover cover_of(const tdt_compute *c, int width, int height) {
+  Cover k;
+  k.groups_x = width / 32 < 1 ? 1 : width / 32;
+  k.groups_y = height / 32 < 1 ? 1 : height / 32;
+  long cw = (long)k.groups_x * 32, ch = (long)k.groups_y * 32;
+  k.cover_w = (int)(cw < c->image_width ? cw : c->image_width);
+  k.cover_h = (int)(ch < c->image_height ? ch : c->image_height);
+  if (k.cover_w < 0) k.cover_w = 0;
+  if (k.cover_h < 0) k.cover_h = 0;
+  return k;
+}
+// work-group rows this rank owns among ceil(cover_h/32), and the pixel rows they hold
+int owned_group_rows(const tdt_compute *c, int cover_h) {
+  int gy = (cover_h + 31) / 32;
+  return gy > c->part_rank ? (gy - c->part_rank + c->part_world - 1) / c->part_world : 0;
+}
+int owned_pixel_rows(const tdt_compute *c, int cover_h) {
+  int n = owned_group_rows(c, cover_h), rows = 0;
+  for (int k = 0; k < n; k++) {
+    int y0 = (c->part_rank + k * c->part_world) * 32;
+    int left = cover_h - y0;
+    rows += left >= 32 ? 32 : (left > 0 ? left : 0);
+  }
+  return rows;
+}
+
+int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_begin, int spp_count, void *carry,
+           int total_spp) {
+  tdt_ctx *ctx = c->ctx;
+  (void)depth;   // raytracer.comp is a 2-D dispatch: groups_z = max(depth / 1, 1) layers all write the same pixels
+  static const int required[] = {TDT_SLOT_CELLS, TDT_SLOT_MATERIALS, TDT_SLOT_ALBEDOS, TDT_SLOT_METAL,
+                                 TDT_SLOT_DIELECTRIC, TDT_SLOT_OCTREE_FLOATS, TDT_SLOT_OCTREE_INTS};
+  for (int s : required)
+    if (!ctx->ssbo[s]) return fail(ctx, TDT_ERR_INCOMPLETE, "no buffer bound to shader-storage slot " + std::to_string(s));
+  if (!ctx->image0) return fail(ctx, TDT_ERR_INCOMPLETE, "no image bound to unit 0");
+  if (ctx->ssbo[TDT_SLOT_OCTREE_FLOATS]->bytes < 28 || ctx->ssbo[TDT_SLOT_OCTREE_INTS]->bytes < 12)
+    return fail(ctx, TDT_ERR_INVALID_VALUE, "octree uniform buffers are too small (need 28 / 12 bytes)");
+  tdt_image *img = ctx->image0;
+  if (img->w != c->image_width)
+    return fail(ctx, TDT_ERR_INVALID_OPERATION, "bound image width differs from camera.image_width");
+
+  TraceParams P;
+  std::memset(&P, 0, sizeof P);
+  P.image_width = c->image_width; P.image_height = c->image_height;
+  for (int i = 0; i < 3; i++) {
+    P.hor[i] = c->horizontal[i]; P.ver[i] = c->vertical[i]; P.llc[i] = c->lower_left_corner[i]; P.org[i] = c->origin[i];
+  }
+  P.samples_per_pixel = c->samples_per_pixel; P.max_bounce = c->max_bounce;
+  float of[7]; int32_t oi[3];
+  std::memcpy(of, ctx->ssbo[TDT_SLOT_OCTREE_FLOATS]->shadow, sizeof of);
+  std::memcpy(oi, ctx->ssbo[TDT_SLOT_OCTREE_INTS]->shadow, sizeof oi);
+  P.min_x = of[0]; P.min_y = of[1]; P.min_z = of[2]; P.scale = of[4]; P.inv_scale = of[5]; P.inv_cell_count = of[6];
+  P.max_depth = oi[0]; P.max_iter = oi[1]; P.cell_count = oi[2];
+  auto dwords = [](const tdt_buffer *b) { size_t d = b->bytes >> 2; return (uint32_t)(d > 0xFFFFFFFFull ? 0xFFFFFFFFull : d); };
+  P.cells = (const uint32_t *)ctx->ssbo[TDT_SLOT_CELLS]->dev; P.cells_dwords = dwords(ctx->ssbo[TDT_SLOT_CELLS]);
+  P.materials = (const uint32_t *)ctx->ssbo[TDT_SLOT_MATERIALS]->dev; P.materials_dwords = dwords(ctx->ssbo[TDT_SLOT_MATERIALS]);
+  P.albedos = (const uint32_t *)ctx->ssbo[TDT_SLOT_ALBEDOS]->dev; P.albedos_dwords = dwords(ctx->ssbo[TDT_SLOT_ALBEDOS]);
+  P.metal = (const uint32_t *)ctx->ssbo[TDT_SLOT_METAL]->dev; P.metal_dwords = dwords(ctx->ssbo[TDT_SLOT_METAL]);
+  P.dielectric = (const uint32_t *)ctx->ssbo[TDT_SLOT_DIELECTRIC]->dev; P.dielectric_dwords = dwords(ctx->ssbo[TDT_SLOT_DIELECTRIC]);
+  P.image = img->dev; P.carry = (float *)carry;
+  Cover k = cover_of(c, width, height);
+  P.cover_w = k.cover_w; P.cover_h = k.cover_h;
+  P.part_rank = c->part_rank; P.part_world = c->part_world;
+  const int own_rows = owned_pixel_rows(c, k.cover_h);
+  if (img->h == c->image_height) { P.compact = 0; P.image_rows = img->h; }
+  else if (c->part_world > 1 && img->h >= own_rows) { P.compact = 1; P.image_rows = img->h; }
+  else return fail(ctx, TDT_ERR_INVALID_OPERATION, "bound image height is neither camera.image_height nor this rank's tile rows");
+  P.spp_begin = spp_begin; P.spp_count = spp_count; P.mode = mode; P.total_spp = total_spp;
+
+  const int n_groups = owned_group_rows(c, k.cover_h);
+  if (n_groups <= 0 || k.cover_w <= 0) return TDT_OK;
+  dim3 grid((unsigned)((k.cover_w + 15) / 16), (unsigned)(n_groups * 2), 1), block(256, 1, 1);
+  TDT_HIP(ctx, hipSetDevice(ctx->device));
+  if (mode == 0) hipLaunchKernelGGL(tdt::trace_kernel<0>, grid, block, 0, ctx->stream, P);
+  else if (mode == 1) hipLaunchKernelGGL(tdt::trace_kernel<1>, grid, block, 0, ctx->stream, P);
+  else hipLaunchKernelGGL(tdt::resolve_kernel, grid, block, 0, ctx->stream, P);
+  TDT_HIP(ctx, hipGetLastError());
+  return TDT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
+  if (!out) return fail(nullptr, TDT_ERR_INVALID_VALUE, "null out pointer");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(nullptr, TDT_ERR_NO_DEVICE, std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+  if (device_id < 0 || device_id >= n) return fail(nullptr, TDT_ERR_INVALID_VALUE, "device id out of range");
+  e = hipSetDevice(device_id);
+  if (e != hipSuccess) return fail(nullptr, TDT_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  tdt_ctx *ctx = new (std::nothrow) tdt_ctx();
+  if (!ctx) return fail(nullptr, TDT_ERR_HIP, "out of host memory");
+  ctx->device = device_id;
+  for (auto &s : ctx->ssbo) s = nullptr;
+  ctx->atomic0 = nullptr; ctx->image0 = nullptr;
+  if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
+  else {
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return fail(nullptr, TDT_ERR_NO_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    ctx->own_stream = true;
+  }
+  *out = ctx;
+  return TDT_OK;
+}
+
+void tdt_ctx_destroy(tdt_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (tdt_compute *c : ctx->computes) delete c;
+  for (tdt_buffer *b : ctx->buffers) { (void)hipFree(b->dev); delete b; }
+  for (tdt_image *i : ctx->images) { if (i->owned) (void)hipFree(i->dev); delete i; }
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int tdt_finish(tdt_ctx *ctx) {
+  if (!ctx) return TDT_ERR_INVALID_VALUE;
+  TDT_HIP(ctx, hipSetDevice(ctx->device));
+  TDT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return TDT_OK;
+}
+
+const char *tdt_last_error(const tdt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+const char *tdt_strerror(int code) {
+  switch (code) {
+    case TDT_OK: return "ok";
+    case TDT_ERR_NO_DEVICE: return "no usable HIP device";
+    case TDT_ERR_HIP: return "HIP runtime error";
+    case TDT_ERR_INVALID_ENUM: return "gl error: invalid enum";            // mod.rs:47
+    case TDT_ERR_INVALID_VALUE: return "gl error: invalid value";          // mod.rs:48
+    case TDT_ERR_INVALID_OPERATION: return "gl error: invalid operation";  // mod.rs:49
+    case TDT_ERR_VARIABLE_NOT_FOUND: return "failed to locate uniform";    // mod.rs:53-54
+    case TDT_ERR_INCOMPLETE: return "dispatch with a missing binding";
+    default: return "unknown error code";
+  }
+}
+
+int tdt_compute_create(tdt_ctx *ctx, int kind, tdt_compute **out) {
+  if (!ctx || !out) return fail(ctx, TDT_ERR_INVALID_VALUE, "null argument");
+  *out = nullptr;
+  if (kind != TDT_PROGRAM_RAYTRACER)
+    return fail(ctx, TDT_ERR_INVALID_ENUM, "only TDT_PROGRAM_RAYTRACER is built (octree_update.comp is a next row, SURVEY §8f-2)");
+  tdt_compute *c = new (std::nothrow) tdt_compute();
+  if (!c) return fail(ctx, TDT_ERR_HIP, "out of host memory");
+  std::memset(c, 0, sizeof *c);
+  c->ctx = ctx; c->kind = kind; c->part_rank = 0; c->part_world = 1;
+  ctx->computes.push_back(c);
+  *out = c;
+  return TDT_OK;
+}
+
+void tdt_compute_destroy(tdt_compute *c) {
+  if (!c) return;
+  erase_from(c->ctx->computes, c);
+  delete c;
+}
+
+int tdt_compute_group_size(const tdt_compute *c, int out[3]) {
+  if (!c || !out) return TDT_ERR_INVALID_VALUE;
+  out[0] = 32; out[1] = 32; out[2] = 1;   // layout(local_size_x = 32, local_size_y = 32) raytracer.comp:3
+  return TDT_OK;
+}
+
+static int not_found(tdt_compute *c, const char *name, const char *type) {
+  // InitializeErr::TypedVariableNotFound's Display, mod.rs:54
+  return fail(c->ctx, TDT_ERR_VARIABLE_NOT_FOUND, std::string("failed to locate uniform ") + (name ? name : "(null)") + " with type " + type);
+}
+
+int tdt_set_i32(tdt_compute *c, const char *name, int32_t v) {
+  if (!c) return TDT_ERR_INVALID_VALUE;
+  if (name) {
+    if (!std::strcmp(name, "camera.image_width")) { c->image_width = v; return TDT_OK; }
+    if (!std::strcmp(name, "camera.image_height")) { c->image_height = v; return TDT_OK; }
+    if (!std::strcmp(name, "camera.samples_per_pixel")) { c->samples_per_pixel = v; return TDT_OK; }
+    if (!std::strcmp(name, "camera.max_bounce")) { c->max_bounce = v; return TDT_OK; }
+  }
+  return not_found(c, name, "i32");
+}
+
+int tdt_set_f32(tdt_compute *c, const char *name, float) {
+  if (!c) return TDT_ERR_INVALID_VALUE;
+  return not_found(c, name, "f32");   // raytracer.comp has no float uniform (set_f32 is unused: program.rs:61)
+}
+
+int tdt_set_vec3f(tdt_compute *c, const char *name, float x, float y, float z) {
+  if (!c) return TDT_ERR_INVALID_VALUE;
+  float *dst = nullptr;
+  if (name) {
+    if (!std::strcmp(name, "camera.horizontal")) dst = c->horizontal;
+    else if (!std::strcmp(name, "camera.vertical")) dst = c->vertical;
+    else if (!std::strcmp(name, "camera.lower_left_corner")) dst = c->lower_left_corner;
+    else if (!std::strcmp(name, "camera.origin")) dst = c->origin;
+  }
+  if (!dst) return not_found(c, name, "vec3 f32");
+  dst[0] = x; dst[1] = y; dst[2] = z;
+  return TDT_OK;
+}
+
+int tdt_set_vec3i(tdt_compute *c, const char *name, int32_t, int32_t, int32_t) {
+  if (!c) return TDT_ERR_INVALID_VALUE;
+  return not_found(c, name, "vec3 i32");   // no ivec3 uniform in raytracer.comp (set_vector3_i32 is unused: program.rs:48)
+}
+
+int tdt_buffer_create(tdt_ctx *ctx, const void *data, size_t bytes, tdt_buffer **out) {
+  if (!ctx || !out) return fail(ctx, TDT_ERR_INVALID_VALUE, "null argument");
+  *out = nullptr;
+  if (bytes && !data) return fail(ctx, TDT_ERR_INVALID_VALUE, "null data with non-zero size");
+  tdt_buffer *b = new (std::nothrow) tdt_buffer();
+  if (!b) return fail(ctx, TDT_ERR_HIP, "out of host memory");
+  b->ctx = ctx; b->bytes = bytes; b->dev = nullptr;
+  std::memset(b->shadow, 0, sizeof b->shadow);
+  TDT_HIP(ctx, hipSetDevice(ctx->device));
+  // 16 bytes of zero slack so that the widest load at the last valid dword stays inside the allocation
+  hipError_t e = hipMalloc(&b->dev, bytes + 16);
+  if (e != hipSuccess) { delete b; return hip_fail(ctx, e, "hipMalloc"); }
+  e = hipMemsetAsync((char *)b->dev + bytes, 0, 16, ctx->stream);
+  if (e == hipSuccess && bytes) e = hipMemcpyAsync(b->dev, data, bytes, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // glBufferData semantics: `data` may be freed on return
+  if (e != hipSuccess) { (void)hipFree(b->dev); delete b; return hip_fail(ctx, e, "upload"); }
+  std::memcpy(b->shadow, data, bytes < sizeof b->shadow ? bytes : sizeof b->shadow);
+  ctx->buffers.push_back(b);
+  *out = b;
+  return TDT_OK;
+}
+
+void tdt_buffer_destroy(tdt_buffer *b) {
+  if (!b) return;
+  tdt_ctx *ctx = b->ctx;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto &s : ctx->ssbo) if (s == b) s = nullptr;
+  if (ctx->atomic0 == b) ctx->atomic0 = nullptr;
+  erase_from(ctx->buffers, b);
+  (void)hipFree(b->dev);
+  delete b;
+}
+
+int tdt_bind_buffer_base(tdt_ctx *ctx, int target, unsigned slot, tdt_buffer *b) {
+  if (!ctx) return TDT_ERR_INVALID_VALUE;
+  if (b && b->ctx != ctx) return fail(ctx, TDT_ERR_INVALID_OPERATION, "buffer belongs to another context");
+  if (target == TDT_SHADER_STORAGE_BUFFER) {
+    if (slot >= (unsigned)kNumSlots) return fail(ctx, TDT_ERR_INVALID_VALUE, "shader-storage slot out of range (0..7)");
+    ctx->ssbo[slot] = b;
+    return TDT_OK;
+  }
+  if (target == TDT_ATOMIC_COUNTER_BUFFER) {
+    if (slot != 0) return fail(ctx, TDT_ERR_INVALID_VALUE, "atomic-counter slot out of range (0)");
+    ctx->atomic0 = b;
+    return TDT_OK;
+  }
+  return fail(ctx, TDT_ERR_INVALID_ENUM, "unknown buffer target");
+}
+
+int tdt_buffer_sub_data(tdt_buffer *b, size_t offset, size_t bytes, const void *data) {
+  if (!b) return TDT_ERR_INVALID_VALUE;
+  tdt_ctx *ctx = b->ctx;
+  if (offset > b->bytes || bytes > b->bytes - offset) return fail(ctx, TDT_ERR_INVALID_VALUE, "sub-data range outside the buffer");
+  if (!bytes) return TDT_OK;
+  if (!data) return fail(ctx, TDT_ERR_INVALID_VALUE, "null data");
+  TDT_HIP(ctx, hipSetDevice(ctx->device));
+  TDT_HIP(ctx, hipMemcpyAsync((char *)b->dev + offset, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+  TDT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (offset < sizeof b->shadow) {
+    size_t n = sizeof b->shadow - offset; if (n > bytes) n = bytes;
+    std::memcpy(b->shadow + offset, data, n);
+  }
+  return TDT_OK;
+}
+
+int tdt_image_create_rgba32f(tdt_ctx *ctx, int width, int height, tdt_image **out) {
+  if (!ctx || !out) return fail(ctx, TDT_ERR_INVALID_VALUE, "null argument");
+  *out = nullptr;
+  if (width <= 0 || height <= 0) return fail(ctx, TDT_ERR_INVALID_VALUE, "image size must be positive");
+  tdt_image *img = new (std::nothrow) tdt_image();
+  if (!img) return fail(ctx, TDT_ERR_HIP, "out of host memory");
+  img->ctx = ctx; img->w = width; img->h = height; img->owned = true; img->dev = nullptr;
+  size_t bytes = (size_t)width * height * 16;
+  TDT_HIP(ctx, hipSetDevice(ctx->device));
+  hipError_t e = hipMalloc((void **)&img->dev, bytes);
+  if (e == hipSuccess) e = hipMemsetAsync(img->dev, 0, bytes, ctx->stream);
+  if (e != hipSuccess) { if (img->dev) (void)hipFree(img->dev); delete img; return hip_fail(ctx, e, "image allocation"); }
+  ctx->images.push_back(img);
+  *out = img;
+  return TDT_OK;
+}
+
+int tdt_image_wrap_device(tdt_ctx *ctx, void *device_ptr, int width, int height, tdt_image **out) {
+  if (!ctx || !out) return fail(ctx, TDT_ERR_INVALID_VALUE, "null argument");
+  *out = nullptr;
+  if (!device_ptr || width <= 0 || height <= 0) return fail(ctx, TDT_ERR_INVALID_VALUE, "bad device pointer or size");
+  if (((uintptr_t)device_ptr & 15) != 0) return fail(ctx, TDT_ERR_INVALID_VALUE, "image memory must be 16-byte aligned");
+  tdt_image *img = new (std::nothrow) tdt_image();
+  if (!img) return fail(ctx, TDT_ERR_HIP, "out of host memory");
+  img->ctx = ctx; img->w = width; img->h = height; img->owned = false; img->dev = (float *)device_ptr;
+  ctx->images.push_back(img);
+  *out = img;
+  return TDT_OK;
+}
+
+void tdt_image_destroy(tdt_image *img) {
+  if (!img) return;
+  tdt_ctx *ctx = img->ctx;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->image0 == img) ctx->image0 = nullptr;
+  erase_from(ctx->images, img);
+  if (img->owned) (void)hipFree(img->dev);
+  delete img;
+}
+
+int tdt_bind_image(tdt_ctx *ctx, unsigned unit, tdt_image *img) {
+  if (!ctx) return TDT_ERR_INVALID_VALUE;
+  if (unit != 0) return fail(ctx, TDT_ERR_INVALID_VALUE, "only image unit 0 exists (raytracer.comp:4)");
+  if (img && img->ctx != ctx) return fail(ctx, TDT_ERR_INVALID_OPERATION, "image belongs to another context");
+  ctx->image0 = img;
+  return TDT_OK;
+}
+
+int tdt_image_width(const tdt_image *img) { return img ? img->w : 0; }
+int tdt_image_height(const tdt_image *img) { return img ? img->h : 0; }
+void *tdt_image_device_ptr(const tdt_image *img) { return img ? img->dev : nullptr; }
+
+int tdt_image_read(tdt_image *img, float *dst) {
+  if (!img || !dst) return TDT_ERR_INVALID_VALUE;
+  tdt_ctx *ctx = img->ctx;
+  TDT_HIP(ctx, hipSetDevice(ctx->device));
+  TDT_HIP(ctx, hipMemcpyAsync(dst, img->dev, (size_t)img->w * img->h * 16, hipMemcpyDeviceToHost, ctx->stream));
+  TDT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return TDT_OK;
+}
+
+int tdt_dispatch_compute(tdt_compute *c, int width, int height, int depth) {
+  if (!c) return TDT_ERR_INVALID_VALUE;
+  return launch(c, width, height, depth, 0, 0, c->samples_per_pixel, nullptr, c->samples_per_pixel);
+}
+
+int tdt_set_partition(tdt_compute *c, int rank, int world) {
+  if (!c) return TDT_ERR_INVALID_VALUE;
+  if (world < 1 || rank < 0 || rank >= world) return fail(c->ctx, TDT_ERR_INVALID_VALUE, "need 0 <= rank < world");
+  c->part_rank = rank; c->part_world = world;
+  return TDT_OK;
+}
+
+int tdt_dispatch_accumulate(tdt_compute *c, int width, int height, int depth, int spp_begin, int spp_count, void *carry) {
+  if (!c) return TDT_ERR_INVALID_VALUE;
+  if (spp_begin < 0 || spp_count < 0) return fail(c->ctx, TDT_ERR_INVALID_VALUE, "negative sample range");
+  if (carry && ((uintptr_t)carry & 15) != 0) return fail(c->ctx, TDT_ERR_INVALID_VALUE, "carry memory must be 16-byte aligned");
+  return launch(c, width, height, depth, 1, spp_begin, spp_count, carry, 0);
+}
+
+int tdt_dispatch_resolve(tdt_compute *c, int width, int height, int depth, int total_spp) {
+  if (!c) return TDT_ERR_INVALID_VALUE;
+  return launch(c, width, height, depth, 2, 0, 0, nullptr, total_spp);
+}
+
+int64_t tdt_covered_pixels(const tdt_compute *c, int width, int height, int depth) {
+  (void)depth;
+  if (!c) return 0;
+  Cover k = cover_of(c, width, height);
+  return (int64_t)k.cover_w * owned_pixel_rows(c, k.cover_h);
+}
+
+}  // extern "C"

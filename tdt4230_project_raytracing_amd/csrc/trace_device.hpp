@@ -1,0 +1,386 @@
+// Device-side arithmetic of the voxel path trace for gfx950.
+//
+// Every function states the reference lines it implements (rc:N = /root/reference/
+// assets/shaders/raytracer.comp line N).  The integrand is chaotic (each hash feeds on the
+// bits of the previous hit point), so the arithmetic keeps the exact fp32 operation order of
+// the reference as it is compiled for its only runnable target (Mesa/llvmpipe): unfused
+// mul+add (build with -ffp-contract=off), IEEE divide / sqrt, z-y-x dot accumulation, and the
+// polynomial sin/cos/pow of that implementation (the only places that fuse).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "trace_params.h"
+
+namespace tdt {
+
+#define TDT_DEV __device__ __forceinline__
+
+TDT_DEV float f_fract(float x) { return x - __builtin_floorf(x); }
+TDT_DEV float f_rcp(float x) { return 1.0f / x; }                          // IEEE-rounded
+TDT_DEV float f_rsq(float x) { return 1.0f / __builtin_sqrtf(x); }          // two roundings, as the reference
+// min/max where a NaN operand yields the other operand (and ties return b)
+TDT_DEV float f_min(float a, float b) { return (b != b) ? a : (a < b ? a : b); }
+TDT_DEV float f_max(float a, float b) { return (b != b) ? a : (a > b ? a : b); }
+TDT_DEV float b2f(bool b) { return b ? 1.0f : 0.0f; }
+TDT_DEV int32_t f2i(float f) {   // truncating convert; out of range / NaN -> INT_MIN
+  return (f > -2147483904.0f && f < 2147483648.0f) ? (int32_t)f : (int32_t)0x80000000;
+}
+
+// sin/cos: octant reduction + two short polynomials with fused steps (the form the reference
+// target evaluates; needed bit-for-bit because fract(sin(x)*43758.5453) is the RNG, rc:53)
+TDT_DEV void sincos_poly(float a, float &s_out, float &c_out) {
+  float x = __builtin_fabsf(a);
+  int32_t j = f2i(x * 1.27323954473516f);
+  j = (j + 1) & ~1;
+  float y = (float)j;
+  x = __builtin_fmaf(y, -0.78515625f, x);
+  x = __builtin_fmaf(y, -2.4187564849853515625e-4f, x);
+  x = __builtin_fmaf(y, -3.77489497744594108e-8f, x);
+  float z = x * x;
+  float c = 2.443315711809948e-5f;
+  c = __builtin_fmaf(c, z, -1.388731625493765e-3f);
+  c = __builtin_fmaf(c, z, 4.166664568298827e-2f);
+  c = c * z;
+  c = c * z;
+  c = __builtin_fmaf(-0.5f, z, c);
+  c = c + 1.0f;
+  float s = -1.9515295891e-4f;
+  s = __builtin_fmaf(s, z, 8.3321608736e-3f);
+  s = __builtin_fmaf(s, z, -1.6666654611e-1f);
+  s = s * z;
+  s = __builtin_fmaf(s, x, x);
+  float rs = ((j & 2) == 0) ? s : c;
+  bool neg_s = (((j & 4) != 0) != ((__float_as_uint(a) >> 31) != 0));
+  s_out = neg_s ? -rs : rs;
+  int32_t k = j - 2;
+  float rc = ((k & 2) == 0) ? s : c;
+  c_out = (((~k) & 4) != 0) ? -rc : rc;
+}
+TDT_DEV float sin_poly(float a) { float s, c; sincos_poly(a, s, c); return s; }
+
+// pow(x,y) = exp2(log2(x)*y) with the reference target's polynomials (only use: rc:496)
+TDT_DEV float pow_poly(float x, float yy) {
+  uint32_t u = __float_as_uint(x);
+  float e = (float)((int32_t)((u >> 23) & 0xff) - 127);
+  float m = __uint_as_float((u & 0x007fffffu) | 0x3f800000u);
+  float t = (m - 1.0f) / (m + 1.0f);
+  float z = t * t;
+  float z2 = z * z;
+  float even = __builtin_fmaf(z2, __builtin_fmaf(z2, 0.406718052498846252698f, 0.577440339438736392009f), 2.88539009343309178325f);
+  float odd = __builtin_fmaf(z2, 0.403343858251329912514f, 0.961791550404184197881f);
+  float p = __builtin_fmaf(odd, z, even);
+  float l2 = __builtin_fmaf(t, p, e);
+  float w = l2 * yy;
+  w = f_min(f_max(w, -126.99999f), 128.0f);
+  float i = __builtin_floorf(w);
+  float f = w - i;
+  float f2 = f * f;
+  float ev = __builtin_fmaf(f2, __builtin_fmaf(f2, 0.00898934009049466391101f, 0.240153617044375388211f), 1.0f);
+  float od = __builtin_fmaf(f2, __builtin_fmaf(f2, 0.00187757667519147912699f, 0.0558263180532956664775f), 0.693153073200168932794f);
+  float q = __builtin_fmaf(od, f, ev);
+  int32_t ii = f2i(i);
+  return __uint_as_float((uint32_t)(ii + 127) << 23) * q;
+}
+
+// SSBO read with robust-access semantics: dword index outside the buffer reads 0
+TDT_DEV uint32_t ld_dw(const uint32_t *buf, uint32_t dwords, uint32_t byte_off) {
+  uint32_t i = byte_off >> 2;
+  return (i < dwords) ? buf[i] : 0u;
+}
+
+struct Ray { float ox, oy, oz, dx, dy, dz; };
+// what one CubeHit call site last produced (rc:336-354); the root and leaf call sites keep
+// theirs across calls, because on a miss the reference's out-parameter copy hands back the
+// previous contents (see oracle/pathtrace_oracle.c)
+struct HitTmp { float nx, ny, nz, px, py, pz; bool ff; };
+struct Carry { HitTmp root; float root_t; HitTmp leaf; };
+struct Hit { float px, py, pz, nx, ny, nz; bool ff; uint32_t index; };
+
+// CubeHit's record for entry parameter t (rc:336-354)
+TDT_DEV void cube_hit_record(const Ray &r, float t, float cx, float cy, float cz, float size, HitTmp &h) {
+  float px = t * r.dx + r.ox, py = t * r.dy + r.oy, pz = t * r.dz + r.oz;
+  float radius = size * 0.5f;
+  float nx = px + -(cx + radius), ny = py + -(cy + radius), nz = pz + -(cz + radius);
+  float ax = __builtin_fabsf(nx), ay = __builtin_fabsf(ny), az = __builtin_fabsf(nz);
+  nx = nx * b2f(ax >= f_max(ay, az));
+  ny = ny * b2f(f_max(ax, az) < ay);
+  nz = nz * b2f(f_max(ax, ay) < az);
+  float rs = f_rsq((nz * nz + ny * ny) + nx * nx);
+  nx = nx * rs; ny = ny * rs; nz = nz * rs;
+  bool ff = (r.dz * nz + r.dy * ny) < -(r.dx * nx);
+  float flip = -2.0f * b2f(!ff) + 1.0f;
+  nx = nx * flip; ny = ny * flip; nz = nz * flip;
+  rs = f_rsq((nz * nz + ny * ny) + nx * nx);
+  h.nx = nx * rs; h.ny = ny * rs; h.nz = nz * rs;
+  h.ff = ff; h.px = px; h.py = py; h.pz = pz;
+}
+
+// slab test rc:317-331 (t_min / t_max in the first operand slot of the min/max chain)
+TDT_DEV void cube_slabs(const Ray &r, float ix, float iy, float iz, float cx, float cy, float cz, float size,
+                        float t_min, float t_max, float &t_enter, float &t_exit) {
+  float lx = (cx + -r.ox) * ix, ly = (cy + -r.oy) * iy, lz = (cz + -r.oz) * iz;
+  float ux = ((cx + size) + -r.ox) * ix, uy = ((cy + size) + -r.oy) * iy, uz = ((cz + size) + -r.oz) * iz;
+  float mnx = f_min(lx, ux), mny = f_min(ly, uy), mnz = f_min(lz, uz);
+  float mxx = f_max(lx, ux), mxy = f_max(ly, uy), mxz = f_max(lz, uz);
+  t_enter = f_max(f_max(f_max(t_min, mnx), mny), mnz);
+  t_exit = f_min(f_min(f_min(t_max, mxx), mxy), mxz);
+}
+
+// treeLookup rc:359-394: one dependent 8-byte Node load per level
+TDT_DEV bool tree_lookup(const TraceParams &P, float cx, float cy, float cz, float &inv_pow_depth,
+                         float &gx, float &gy, float &gz, uint32_t &value) {
+  float ipd = 1.0f, ux = 0.0f, uy = 0.0f, uz = 0.0f;
+  uint32_t node_value = 0;
+  bool is_leaf = false;
+  const float two_cc = (float)(int32_t)((uint32_t)P.cell_count << 1);
+  const float fdepth = (float)P.max_depth;
+  for (float i = 0.0f; i < fdepth; i = i + 1.0f) {
+    ipd = ipd * 0.5f;
+    float fx = f_fract(cx), fy = f_fract(cy), fz = f_fract(cz);
+    float rx = __builtin_rintf((((float)node_value + fx) * P.inv_cell_count) * two_cc + -0.5f);
+    float ry = __builtin_rintf(fy * 2.0f + -0.5f);
+    float rz = __builtin_rintf(fz * 2.0f + -0.5f);
+    int32_t ix = f2i(rx), iy = f2i(ry), iz = f2i(rz);
+    float tx = __builtin_truncf(rx), ty = __builtin_truncf(ry), tz = __builtin_truncf(rz);
+    float bx = tx + -(2.0f * __builtin_floorf(tx / 2.0f));
+    float by = ty + -(2.0f * __builtin_floorf(ty / 2.0f));
+    float bz = tz + -(2.0f * __builtin_floorf(tz / 2.0f));
+    ux = ux + bx * ipd; uy = uy + by * ipd; uz = uz + bz * ipd;
+    uint32_t idx = (((uint32_t)ix << 1) + (uint32_t)iy);
+    idx = (idx << 1) + (uint32_t)iz;
+    uint32_t dw = (idx << 3) >> 2;
+    uint32_t node_type;
+    if (dw + 1u < P.cells_dwords) {
+      uint2 n = *reinterpret_cast<const uint2 *>(P.cells + dw);
+      node_value = n.x; node_type = n.y;
+    } else {
+      node_value = (dw < P.cells_dwords) ? P.cells[dw] : 0u;
+      node_type = 0u;
+    }
+    if (node_type == 0u || node_type == 2u) { is_leaf = (node_type == 2u); break; }
+    cx = cx * 2.0f; cy = cy * 2.0f; cz = cz * 2.0f;
+  }
+  inv_pow_depth = ipd; gx = ux; gy = uy; gz = uz; value = node_value;
+  return is_leaf;
+}
+
+// OctreeHit rc:397-450 with t_min = 0.0003, t_max = +inf (rc:271)
+TDT_DEV bool octree_hit(const TraceParams &P, const Ray &r, Carry &pc, Hit &hit) {
+  const float inf = __builtin_inff();
+  float ix = f_rcp(r.dx), iy = f_rcp(r.dy), iz = f_rcp(r.dz);
+  float t_enter, t_exit;
+  {
+    float lx = (P.min_x + -r.ox) * ix, ly = (P.min_y + -r.oy) * iy, lz = (P.min_z + -r.oz) * iz;
+    float ux = ((P.min_x + P.scale) + -r.ox) * ix, uy = ((P.min_y + P.scale) + -r.oy) * iy,
+          uz = ((P.min_z + P.scale) + -r.oz) * iz;
+    float mnx = f_min(lx, ux), mny = f_min(ly, uy), mnz = f_min(lz, uz);
+    float mxx = f_max(lx, ux), mxy = f_max(ly, uy), mxz = f_max(lz, uz);
+    t_enter = f_max(f_max(f_max(mnx, 0.0003f), mny), mnz);
+    t_exit = f_min(f_min(f_min(mxx, inf), mxy), mxz);
+  }
+  float t_octree_max = inf;
+  if (t_exit >= t_enter) {
+    cube_hit_record(r, t_enter, P.min_x, P.min_y, P.min_z, P.scale, pc.root);
+    pc.root_t = t_enter;
+    t_octree_max = t_exit;
+  }
+  float t_stride = pc.root_t;
+  float inv_pow_depth = 0.5f;
+  for (int32_t i = 0; i < P.max_iter && t_stride < t_octree_max; i++) {
+    float adv = f_max(0.0001f * (inv_pow_depth + 0.1f), 0.000001f);
+    float t = t_stride + adv;
+    float wx = t * r.dx + r.ox, wy = t * r.dy + r.oy, wz = t * r.dz + r.oz;
+    float lx = (wx + -P.min_x) * P.inv_scale, ly = (wy + -P.min_y) * P.inv_scale, lz = (wz + -P.min_z) * P.inv_scale;
+    {
+      float ex = f_fract(lx) + -lx, ey = f_fract(ly) + -ly, ez = f_fract(lz) + -lz;
+      if ((__builtin_fabsf(ez) + __builtin_fabsf(ey)) != -__builtin_fabsf(ex)) return false;
+    }
+    float gx, gy, gz; uint32_t value;
+    bool leaf = tree_lookup(P, lx, ly, lz, inv_pow_depth, gx, gy, gz, value);
+    if (leaf) {
+      if (i > 0) {
+        float cx = gx * P.scale + P.min_x, cy = gy * P.scale + P.min_y, cz = gz * P.scale + P.min_z;
+        float cs = P.scale * inv_pow_depth;
+        cube_slabs(r, ix, iy, iz, cx, cy, cz, cs, t_stride, t_octree_max, t_enter, t_exit);
+        if (!(t_exit < t_enter)) cube_hit_record(r, t_enter, cx, cy, cz, cs, pc.leaf);
+      }
+      const HitTmp &src = (i > 0) ? pc.leaf : pc.root;
+      hit.px = src.px; hit.py = src.py; hit.pz = src.pz;
+      hit.nx = src.nx; hit.ny = src.ny; hit.nz = src.nz;
+      hit.ff = src.ff; hit.index = value;
+      return true;
+    }
+    float cx = (gx * P.scale + P.min_x) + -0.00001f, cy = (gy * P.scale + P.min_y) + -0.00001f,
+          cz = (gz * P.scale + P.min_z) + -0.00001f;
+    float cs = P.scale * inv_pow_depth + 0.00002f;
+    cube_slabs(r, ix, iy, iz, cx, cy, cz, cs, t_stride, t_octree_max, t_enter, t_exit);
+    t_stride = (!(t_exit < t_enter)) ? t_exit : t_octree_max;
+  }
+  return false;
+}
+
+TDT_DEV float rand2(float cx, float cy) {   // Rand(vec2) rc:53
+  return f_fract(sin_poly(cy * 78.233f + cx * 12.9898f) * 43758.5453f);
+}
+
+TDT_DEV void load_albedo(const TraceParams &P, uint32_t mo, float &ar, float &ag, float &ab) {   // AlbedoColor rc:309-313
+  uint32_t ai = ld_dw(P.materials, P.materials_dwords, mo + 8u) * 12u;
+  ar = __uint_as_float(ld_dw(P.albedos, P.albedos_dwords, ai));
+  ag = __uint_as_float(ld_dw(P.albedos, P.albedos_dwords, ai + 4u));
+  ab = __uint_as_float(ld_dw(P.albedos, P.albedos_dwords, ai + 8u));
+}
+
+// switch (materials[hit.index].type) rc:278-291; returns false when the path ends
+TDT_DEV bool scatter(const TraceParams &P, const Ray &r, const Hit &h, Ray &out, float &ar, float &ag, float &ab) {
+  uint32_t mo = h.index * 12u;
+  int32_t type = (int32_t)ld_dw(P.materials, P.materials_dwords, mo);
+  float dx = r.dx, dy = r.dy, dz = r.dz;
+  float nx = h.nx, ny = h.ny, nz = h.nz;
+  out.ox = h.px; out.oy = h.py; out.oz = h.pz;
+  if (type == 0) {   // ScatterLambertian rc:470-482, constructFrisvad rc:453-468, SampleGGXVNDF rc:27-49
+    float rs = f_rsq((nz * nz + ny * ny) + nx * nx);
+    float mx = nx * rs, my = ny * rs, mz = nz * rs;
+    bool sing = nz < -0.9999f;
+    float a = f_rcp(1.0f + nz);
+    float b = -((nx * ny) * a);
+    float r0x = 1.0f + -((nx * nx) * a);
+    float r2y = 1.0f + -((ny * ny) * a);
+    float e_b = sing ? -1.0f : b;
+    float e_r2y = sing ? 0.0f : r2y;
+    float e_r2z = sing ? 0.0f : -ny;
+    float e_r0x = sing ? 0.0f : r0x;
+    float e_r0z = sing ? 0.0f : -nx;
+    float vx = (dz * e_r0z + dy * e_b) + dx * e_r0x;
+    float vy = (dz * mz + dy * my) + dx * mx;
+    float vz = (dz * e_r2z + dy * e_r2y) + dx * e_b;
+    // hash23(point * 100 + 0) rc:85-90,230-232 ("*100" and the hash scale folded in fp32)
+    float p3x = f_fract((100.0f * .1031f) * h.px), p3y = f_fract((100.0f * .1030f) * h.py),
+          p3z = f_fract((100.0f * .0973f) * h.pz);
+    float d = (p3z * (p3x + 33.33f) + p3y * (p3z + 33.33f)) + p3x * (p3y + 33.33f);
+    p3x = p3x + d; p3y = p3y + d; p3z = p3z + d;
+    float U0 = f_fract((p3x + p3y) * p3z), U1 = f_fract((p3x + p3z) * p3y);
+    float sx = vx * 0.85f, sy = vy * 0.85f;
+    rs = f_rsq((vz * vz + sy * sy) + sx * sx);
+    float va = sx * rs, vb = sy * rs, vc = vz * rs;      // Vh = (-va,-vb,-vc)
+    float vhz = -vc;
+    float lensq = va * va + vb * vb;
+    bool nzl = 0.0f < lensq;
+    float rl = f_rsq(lensq);
+    float t1x = nzl ? vb * rl : 1.0f;
+    float t1y = nzl ? -(va * rl) : 0.0f;
+    float rr = __builtin_sqrtf(U0);
+    float phi = (2.0f * 3.14159265358f) * U1;
+    float sn, cs; sincos_poly(phi, sn, cs);
+    float t1 = rr * cs, t2 = rr * sn;
+    float s = 0.5f * (1.0f + vhz);
+    float om = 1.0f + -(t1 * t1);
+    t2 = (1.0f + -s) * __builtin_sqrtf(om) + s * t2;
+    float T2x = vc * t1y;
+    float T2yn = vc * t1x;
+    float T2z = -(va * t1y) + vb * t1x;
+    float nhx = t1 * t1x + t2 * T2x;
+    float nhy = t1 * t1y + -(T2yn * t2);
+    float nhz = t2 * T2z;
+    float sq = __builtin_sqrtf(f_max(om + -(t2 * t2), 0.0f));
+    nhx = nhx + -(va * sq); nhy = nhy + -(vb * sq); nhz = nhz + -(vc * sq);
+    float ex = 0.85f * nhx, ey = 0.85f * nhy, ez = f_max(nhz, 0.0f);
+    rs = f_rsq((ez * ez + ey * ey) + ex * ex);
+    ex = ex * rs; ey = ey * rs; ez = ez * rs;
+    float dt = ((ez * dz + ey * dy) + ex * dx) * 2.0f;
+    float qx = nx + (dx + -(dt * ex)), qy = ny + (dy + -(dt * ey)), qz = nz + (dz + -(dt * ez));
+    rs = f_rsq((qz * qz + qy * qy) + qx * qx);
+    out.dx = qx * rs; out.dy = qy * rs; out.dz = qz * rs;
+    load_albedo(P, mo, ar, ag, ab);
+    return true;
+  }
+  if (type == 1) {   // ScatterMetal rc:484-491, RandInHemisphere rc:106-115 (one cube sample, as compiled)
+    float rs = f_rsq((nz * nz + ny * ny) + nx * nx);
+    float mx = nx * rs, my = ny * rs, mz = nz * rs;
+    float dt = ((mz * dz + my * dy) + mx * dx) * 2.0f;
+    float rx = dx + -(dt * mx), ry = dy + -(dt * my), rz = dz + -(dt * mz);
+    uint32_t at = ld_dw(P.materials, P.materials_dwords, mo + 4u);
+    float fuzz = __uint_as_float(ld_dw(P.metal, P.metal_dwords, at << 2));
+    float hx = -1.0f + 2.0f * rand2(h.px, h.py);
+    float hy = -1.0f + 2.0f * rand2(h.px + hx, h.py + hx);
+    float hz = -1.0f + 2.0f * rand2(h.px + hy, h.py + hy);
+    bool same = -(hz * nz + hy * ny) < hx * nx;
+    if (!same) { hx = -hx; hy = -hy; hz = -hz; }
+    float qx = rx + fuzz * hx, qy = ry + fuzz * hy, qz = rz + fuzz * hz;
+    rs = f_rsq((qz * qz + qy * qy) + qx * qx);
+    qx = qx * rs; qy = qy * rs; qz = qz * rs;
+    out.dx = qx; out.dy = qy; out.dz = qz;
+    load_albedo(P, mo, ar, ag, ab);
+    return -(qz * nz + qy * ny) < qx * nx;
+  }
+  if (type == 2) {   // ScatterDielectric rc:499-522, reflectance rc:494-497
+    uint32_t at = ld_dw(P.materials, P.materials_dwords, mo + 4u);
+    float ir = __uint_as_float(ld_dw(P.dielectric, P.dielectric_dwords, at << 2));
+    float ratio = h.ff ? f_rcp(ir) : ir;
+    float pz_ = dz * nz, py_ = dy * ny, px_ = dx * nx;
+    float cos_t = f_min((-pz_ + -py_) + -px_, 1.0f);
+    float sin_t = __builtin_sqrtf(1.0f + -(cos_t * cos_t));
+    bool cannot = 1.0f < ratio * sin_t;
+    float q = (1.0f + -ratio) / (1.0f + ratio);
+    float r0 = q * q;
+    float rnd = rand2(h.px, h.py);
+    float refl = pow_poly(1.0f + -cos_t, 5.0f) * (1.0f + -r0) + r0;
+    float dn = (pz_ + py_) + px_;
+    float ox_, oy_, oz_;
+    if (cannot || (rnd < refl)) {
+      float dt = dn * 2.0f;
+      ox_ = dx + -(dt * nx); oy_ = dy + -(dt * ny); oz_ = dz + -(dt * nz);
+    } else {
+      float k = 1.0f + -(ratio * (ratio * (1.0f + -(dn * dn))));
+      if (!(k < 0.0f)) {
+        float m = ratio * dn + __builtin_sqrtf(k);
+        ox_ = ratio * dx + -(m * nx); oy_ = ratio * dy + -(m * ny); oz_ = ratio * dz + -(m * nz);
+      } else { ox_ = 0.0f; oy_ = 0.0f; oz_ = 0.0f; }
+    }
+    float rs = f_rsq((oz_ * oz_ + oy_ * oy_) + ox_ * ox_);
+    out.dx = ox_ * rs; out.dy = oy_ * rs; out.dz = oz_ * rs;
+    ar = 1.0f; ag = 1.0f; ab = 1.0f;
+    return true;
+  }
+  return false;
+}
+
+// primary ray of sample s at pixel (px,py): rc:240-245, CameraGetRay rc:304-307
+TDT_DEV Ray primary_ray(const TraceParams &P, int px, int py, int s) {
+  float x = (float)px, y = (float)py, fs = (float)s;
+  const float K = 0.2f * .1031f;
+  float a = f_fract(K * (x + fs)), b = f_fract(K * y);
+  float d = (a + 33.33f) * (a + b) + a * (b + 33.33f);
+  float h1 = f_fract(((a + d) + (b + d)) * (a + d));
+  float a2 = f_fract(K * x), b2 = f_fract(K * (y + fs));
+  float d2 = (a2 + 33.33f) * (a2 + b2) + a2 * (b2 + 33.33f);
+  float h2 = f_fract(((a2 + d2) + (b2 + d2)) * (a2 + d2));
+  float u = (x + h1) / (float)(P.image_width - 1);
+  float v = (y + h2) / (float)(P.image_height - 1);
+  float rx = (P.hor[0] * u + P.llc[0]) + (v * P.ver[0] + -P.org[0]);
+  float ry = (P.hor[1] * u + P.llc[1]) + (v * P.ver[1] + -P.org[1]);
+  float rz = (P.hor[2] * u + P.llc[2]) + (v * P.ver[2] + -P.org[2]);
+  float rs = f_rsq((rz * rz + ry * ry) + rx * rx);
+  Ray r = { P.org[0], P.org[1], P.org[2], rx * rs, ry * rs, rz * rs };
+  return r;
+}
+
+// RayColor rc:264-302
+TDT_DEV void ray_color(const TraceParams &P, Ray r, Carry &pc, float &cr, float &cg, float &cb) {
+  float ar = 1.0f, ag = 1.0f, ab = 1.0f;
+  int32_t loop_count = 0;
+  Hit h;
+  while (loop_count < P.max_bounce && octree_hit(P, r, pc, h)) {
+    loop_count += 1;
+    Ray nr; float tr, tg, tb;
+    if (!scatter(P, r, h, nr, tr, tg, tb)) break;
+    ar = ar * tr; ag = ag * tg; ab = ab * tb;
+    r = nr;
+  }
+  if (loop_count > 0) { cr = ar; cg = ag; cb = ab; return; }
+  float yp = r.dy + 1.0f;
+  float w = 1.0f + -(0.5f * yp);
+  cr = w + 0.25f * yp; cg = w + 0.35f * yp; cb = 1.0f;
+}
+
+}  // namespace tdt

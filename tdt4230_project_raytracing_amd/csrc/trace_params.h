@@ -1,0 +1,30 @@
+// Kernel argument block of the trace kernels (passed by value: lands in SGPRs via s_load).
+#pragma once
+#include <stdint.h>
+
+struct TraceParams {
+  // `uniform Camera camera` raytracer.comp:133-146
+  int32_t image_width, image_height;
+  float hor[3], ver[3], llc[3], org[3];
+  int32_t samples_per_pixel, max_bounce;
+  // OctreeFloats / OctreeInts raytracer.comp:150-166 (uniform data: kept in scalar registers
+  // instead of being re-read from the SSBO every traversal step)
+  float min_x, min_y, min_z, scale, inv_scale, inv_cell_count;
+  int32_t max_depth, max_iter, cell_count;
+  // SSBO payloads (device pointers) and their sizes in dwords (reads past the end return 0)
+  const uint32_t *cells;      uint32_t cells_dwords;
+  const uint32_t *materials;  uint32_t materials_dwords;
+  const uint32_t *albedos;    uint32_t albedos_dwords;
+  const uint32_t *metal;      uint32_t metal_dwords;
+  const uint32_t *dielectric; uint32_t dielectric_dwords;
+  // output image (RGBA32F, row 0 = bottom) and optional per-pixel carry (16 floats / pixel)
+  float *image;
+  float *carry;
+  int32_t image_rows;          // rows the bound image really has (full height, or compact tile rows)
+  int32_t compact;             // 1: image holds only this rank's work-group rows, packed
+  int32_t cover_w, cover_h;    // pixels a dispatch covers: min(32*groups, image size)
+  int32_t part_rank, part_world;  // work-group-row partition (r % world == rank)
+  int32_t spp_begin, spp_count;   // sample range of this launch
+  int32_t mode;                // 0 render (sum, sqrt, clamp, store), 1 accumulate into image, 2 resolve
+  int32_t total_spp;           // resolve divisor
+};

@@ -1,0 +1,173 @@
+"""ctypes binding of libtdthost.so (include/tdt_host.h): camera uniforms and scene payloads.
+
+Host-side restatement of the reference's Rust host code — CameraBuilder::build
+(src/renderer/camera.rs:135-196), Octree::init_global_buffers (src/renderer/octree.rs:40-100),
+the demo scene literal (src/main.rs:235-463) — plus the synthetic-scene generators.  Pure
+host code; no HIP, no oracle.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libtdthost.so")
+
+SLOTS = (0, 1, 2, 3, 4, 6, 7)
+SLOT_DTYPES = {0: np.uint32, 1: np.uint32, 2: np.float32, 3: np.float32, 4: np.float32, 6: np.float32, 7: np.int32}
+SLOT_NAMES = {0: "cells", 1: "materials", 2: "albedos", 3: "metal", 4: "dielectric", 6: "octree_floats", 7: "octree_ints"}
+
+
+class CameraBuilderC(ctypes.Structure):
+    _fields_ = [
+        ("vertical_fov", ctypes.c_float), ("image_width", ctypes.c_int32),
+        ("has_aspect_ratio", ctypes.c_int32), ("aspect_ratio", ctypes.c_float),
+        ("has_viewport_height", ctypes.c_int32), ("viewport_height", ctypes.c_float),
+        ("has_origin", ctypes.c_int32), ("origin", ctypes.c_float * 3),
+        ("has_samples_per_pixel", ctypes.c_int32), ("samples_per_pixel", ctypes.c_int32),
+        ("has_max_bounce", ctypes.c_int32), ("max_bounce", ctypes.c_int32),
+    ]
+
+
+class CameraUniforms(ctypes.Structure):
+    """`uniform Camera camera` (raytracer.comp:133-146) as initial_uniforms sends it (camera.rs:241-253)."""
+    _fields_ = [
+        ("image_width", ctypes.c_int32), ("image_height", ctypes.c_int32),
+        ("horizontal", ctypes.c_float * 3), ("vertical", ctypes.c_float * 3),
+        ("lower_left_corner", ctypes.c_float * 3), ("origin", ctypes.c_float * 3),
+        ("samples_per_pixel", ctypes.c_int32), ("max_bounce", ctypes.c_int32),
+    ]
+
+    def copy(self):
+        c = CameraUniforms()
+        ctypes.memmove(ctypes.byref(c), ctypes.byref(self), ctypes.sizeof(self))
+        return c
+
+
+class SceneParams(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("max_depth", ctypes.c_int32), ("cell_count", ctypes.c_int32),
+                ("max_iter", ctypes.c_int32), ("seed", ctypes.c_uint64)]
+
+
+SCENE_HASH_GRID, SCENE_TERRAIN, SCENE_SHELLS = 0, 1, 2
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(f"{_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = ctypes.CDLL(_LIB_PATH)
+        L.tdt_host_last_error.restype = ctypes.c_char_p
+        L.tdt_camera_build.argtypes = [ctypes.POINTER(CameraBuilderC), ctypes.POINTER(CameraUniforms)]
+        L.tdt_camera_reference_pose.argtypes = [ctypes.c_int] * 4 + [ctypes.POINTER(CameraUniforms)]
+        L.tdt_scene_demo.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        L.tdt_scene_generate.argtypes = [ctypes.POINTER(SceneParams), ctypes.POINTER(ctypes.c_void_p)]
+        L.tdt_scene_config.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        L.tdt_scene_from_blobs.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t),
+                                           ctypes.POINTER(ctypes.c_void_p)]
+        L.tdt_scene_destroy.argtypes = [ctypes.c_void_p]
+        L.tdt_scene_destroy.restype = None
+        L.tdt_scene_blob.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]
+        L.tdt_scene_blob.restype = ctypes.c_void_p
+        L.tdt_scene_counts.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError("libtdthost: " + lib().tdt_host_last_error().decode())
+
+
+class Scene:
+    """The seven SSBO payloads of one scene, as numpy arrays (copies) keyed by binding slot."""
+
+    def __init__(self, blobs, counts=None, name=""):
+        self.blobs = {int(k): np.ascontiguousarray(v) for k, v in blobs.items()}
+        self.counts = counts
+        self.name = name
+
+    @classmethod
+    def _from_handle(cls, h, name):
+        L = lib()
+        blobs = {}
+        for slot in SLOTS:
+            n = ctypes.c_size_t(0)
+            p = L.tdt_scene_blob(h, slot, ctypes.byref(n))
+            dt = np.dtype(SLOT_DTYPES[slot])
+            if n.value:
+                buf = (ctypes.c_char * n.value).from_address(p)
+                blobs[slot] = np.frombuffer(buf, dtype=dt).copy()
+            else:
+                blobs[slot] = np.zeros(0, dt)
+        cnt = (ctypes.c_int64 * 6)()
+        _check(L.tdt_scene_counts(h, cnt))
+        L.tdt_scene_destroy(h)
+        keys = ("cells", "parents", "leaves", "empties", "materials", "voxels")
+        return cls(blobs, dict(zip(keys, list(cnt))), name)
+
+    @classmethod
+    def demo(cls):
+        h = ctypes.c_void_p()
+        _check(lib().tdt_scene_demo(ctypes.byref(h)))
+        return cls._from_handle(h, "demo")
+
+    @classmethod
+    def config(cls, n):
+        h = ctypes.c_void_p()
+        _check(lib().tdt_scene_config(int(n), ctypes.byref(h)))
+        return cls._from_handle(h, f"config{n}")
+
+    @classmethod
+    def generate(cls, kind, max_depth, cell_count, max_iter, seed):
+        p = SceneParams(kind, max_depth, cell_count, max_iter, seed)
+        h = ctypes.c_void_p()
+        _check(lib().tdt_scene_generate(ctypes.byref(p), ctypes.byref(h)))
+        return cls._from_handle(h, f"gen{kind}_d{max_depth}_s{seed:x}")
+
+    @property
+    def max_depth(self):
+        return int(self.blobs[7][0])
+
+    @property
+    def max_iter(self):
+        return int(self.blobs[7][1])
+
+    @property
+    def cell_count(self):
+        return int(self.blobs[7][2])
+
+    def nbytes(self):
+        return sum(a.nbytes for a in self.blobs.values())
+
+
+def camera_build(vertical_fov, image_width, aspect_ratio=None, viewport_height=None, origin=None,
+                 samples_per_pixel=None, max_bounce=None):
+    """CameraBuilder::new(fov, width).with_*().build() -> the uniforms it uploads (camera.rs:119-253)."""
+    b = CameraBuilderC()
+    b.vertical_fov = vertical_fov
+    b.image_width = image_width
+    if aspect_ratio is not None:
+        b.has_aspect_ratio, b.aspect_ratio = 1, aspect_ratio
+    if viewport_height is not None:
+        b.has_viewport_height, b.viewport_height = 1, viewport_height
+    if origin is not None:
+        b.has_origin = 1
+        b.origin[:] = list(origin)
+    if samples_per_pixel is not None:
+        b.has_samples_per_pixel, b.samples_per_pixel = 1, samples_per_pixel
+    if max_bounce is not None:
+        b.has_max_bounce, b.max_bounce = 1, max_bounce
+    u = CameraUniforms()
+    _check(lib().tdt_camera_build(ctypes.byref(b), ctypes.byref(u)))
+    return u
+
+
+def camera_reference_pose(width, height, spp, max_bounce):
+    """The camera main.rs:165-168 builds, for a width x height window."""
+    u = CameraUniforms()
+    _check(lib().tdt_camera_reference_pose(width, height, spp, max_bounce, ctypes.byref(u)))
+    return u

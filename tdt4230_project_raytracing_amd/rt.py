@@ -1,0 +1,276 @@
+"""ctypes binding of libtdtrt.so (include/tdt_rt.h) and a Python mirror of the reference's
+`src/renderer` wrapper API over it (same names and argument meaning, so tests read like the
+reference's host code in main.rs:156-470, 579):
+
+    ComputeShader(ctx).dispatch_compute(w, h, d)      compute_shader.rs:15-38
+    Program.set_i32 / set_f32 / set_vector3_f32 / set_vector3_i32     program.rs:35-83
+    VertexBufferObject(ctx, array) + bind_buffer_base(SSBO, slot, vbo)  vbo.rs:32-55, main.rs:352
+    Texture.new_2d(ctx, w, h)                         texture.rs:47-75
+
+There is no fallback: if the library or a HIP device is missing, construction raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtdtrt.so")
+
+OK, ERR_NO_DEVICE, ERR_HIP, ERR_VARIABLE_NOT_FOUND, ERR_INCOMPLETE = 0, 1, 2, 3, 4
+ERR_INVALID_ENUM, ERR_INVALID_VALUE, ERR_INVALID_OPERATION = 0x0500, 0x0501, 0x0502
+PROGRAM_RAYTRACER, PROGRAM_OCTREE_UPDATE = 0, 1
+SHADER_STORAGE_BUFFER, ATOMIC_COUNTER_BUFFER = 0x90D2, 0x92C0
+
+# every symbol include/tdt_rt.h declares: (name, restype, argtypes)
+_P, _I, _U, _F, _S = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_float, ctypes.c_size_t
+_PP = ctypes.POINTER(ctypes.c_void_p)
+SYMBOLS = [
+    ("tdt_ctx_create", _I, [_I, _P, _PP]),
+    ("tdt_ctx_destroy", None, [_P]),
+    ("tdt_finish", _I, [_P]),
+    ("tdt_last_error", ctypes.c_char_p, [_P]),
+    ("tdt_strerror", ctypes.c_char_p, [_I]),
+    ("tdt_compute_create", _I, [_P, _I, _PP]),
+    ("tdt_compute_destroy", None, [_P]),
+    ("tdt_compute_group_size", _I, [_P, ctypes.POINTER(ctypes.c_int)]),
+    ("tdt_set_i32", _I, [_P, ctypes.c_char_p, ctypes.c_int32]),
+    ("tdt_set_f32", _I, [_P, ctypes.c_char_p, _F]),
+    ("tdt_set_vec3f", _I, [_P, ctypes.c_char_p, _F, _F, _F]),
+    ("tdt_set_vec3i", _I, [_P, ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    ("tdt_buffer_create", _I, [_P, _P, _S, _PP]),
+    ("tdt_buffer_destroy", None, [_P]),
+    ("tdt_bind_buffer_base", _I, [_P, _I, _U, _P]),
+    ("tdt_buffer_sub_data", _I, [_P, _S, _S, _P]),
+    ("tdt_image_create_rgba32f", _I, [_P, _I, _I, _PP]),
+    ("tdt_image_wrap_device", _I, [_P, _P, _I, _I, _PP]),
+    ("tdt_image_destroy", None, [_P]),
+    ("tdt_bind_image", _I, [_P, _U, _P]),
+    ("tdt_image_width", _I, [_P]),
+    ("tdt_image_height", _I, [_P]),
+    ("tdt_image_device_ptr", _P, [_P]),
+    ("tdt_image_read", _I, [_P, _P]),
+    ("tdt_dispatch_compute", _I, [_P, _I, _I, _I]),
+    ("tdt_set_partition", _I, [_P, _I, _I]),
+    ("tdt_dispatch_accumulate", _I, [_P, _I, _I, _I, _I, _I, _P]),
+    ("tdt_dispatch_resolve", _I, [_P, _I, _I, _I, _I]),
+    ("tdt_covered_pixels", ctypes.c_int64, [_P, _I, _I, _I]),
+]
+
+_lib = None
+
+
+def lib():
+    """Load libtdtrt.so (raises if it has not been built: there is no other implementation)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
+                               "the trace has no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+class TdtError(RuntimeError):
+    """InitializeErr (renderer/mod.rs:28-33) analogue: carries the integer code of the C ABI."""
+
+    def __init__(self, code, message):
+        super().__init__(f"[{code:#x}] {message}")
+        self.code = code
+
+
+class Context:
+    """The GL context of main.rs:58-61,108-112: one HIP device + stream."""
+
+    def __init__(self, device=0, stream=None):
+        h = ctypes.c_void_p()
+        rc = lib().tdt_ctx_create(int(device), ctypes.c_void_p(stream) if stream else None, ctypes.byref(h))
+        if rc != OK:
+            raise TdtError(rc, lib().tdt_last_error(None).decode())
+        self.h = h
+        self.device = device
+
+    def check(self, rc):
+        if rc != OK:
+            raise TdtError(rc, lib().tdt_last_error(self.h).decode() or lib().tdt_strerror(rc).decode())
+
+    def finish(self):
+        self.check(lib().tdt_finish(self.h))
+
+    def bind_buffer_base(self, target, slot, vbo):
+        """gl::BindBufferBase(target, slot, vbo.id()) — main.rs:352,383,408,430,448; octree.rs:67,98,115,144."""
+        self.check(lib().tdt_bind_buffer_base(self.h, target, slot, vbo.h if vbo is not None else None))
+
+    def close(self):
+        if self.h:
+            lib().tdt_ctx_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class VertexBufferObject:
+    """VertexBufferObject::new::<T>(Vec<T>, ..): glGenBuffers + glBufferData (copies) — vbo.rs:32-55."""
+
+    def __init__(self, ctx, data):
+        a = np.ascontiguousarray(data)
+        h = ctypes.c_void_p()
+        ctx.check(lib().tdt_buffer_create(ctx.h, a.ctypes.data if a.size else None, a.nbytes, ctypes.byref(h)))
+        self.ctx, self.h, self.nbytes = ctx, h, a.nbytes
+
+    def sub_data(self, offset, data):
+        a = np.ascontiguousarray(data)
+        self.ctx.check(lib().tdt_buffer_sub_data(self.h, offset, a.nbytes, a.ctypes.data))
+
+
+class Texture:
+    """Texture::new_2d(TEXTURE0, 0, RGBA32F, RGBA, w, h) + BindImageTexture(unit 0) — texture.rs:47-75."""
+
+    def __init__(self, ctx, h, width, height):
+        self.ctx, self.h, self._w, self._h = ctx, h, width, height
+
+    @classmethod
+    def new_2d(cls, ctx, width, height, bind=True):
+        h = ctypes.c_void_p()
+        ctx.check(lib().tdt_image_create_rgba32f(ctx.h, width, height, ctypes.byref(h)))
+        t = cls(ctx, h, width, height)
+        if bind:
+            t.bind()
+        return t
+
+    @classmethod
+    def wrap_device(cls, ctx, device_ptr, width, height, bind=True):
+        h = ctypes.c_void_p()
+        ctx.check(lib().tdt_image_wrap_device(ctx.h, ctypes.c_void_p(device_ptr), width, height, ctypes.byref(h)))
+        t = cls(ctx, h, width, height)
+        if bind:
+            t.bind()
+        return t
+
+    def bind(self):
+        self.ctx.check(lib().tdt_bind_image(self.ctx.h, 0, self.h))
+
+    def width(self):
+        return self._w
+
+    def height(self):
+        return self._h
+
+    def depth(self):
+        return 1
+
+    def read(self):
+        img = np.empty((self._h, self._w, 4), np.float32)
+        self.ctx.check(lib().tdt_image_read(self.h, img.ctypes.data))
+        return img
+
+
+class Program:
+    """Uniform-by-name setters of program.rs:35-83 (the program object itself is the kernel)."""
+
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def set_i32(self, name, value):
+        self.ctx.check(lib().tdt_set_i32(self.h, name.encode(), int(value)))
+
+    def set_f32(self, name, value):
+        self.ctx.check(lib().tdt_set_f32(self.h, name.encode(), float(value)))
+
+    def set_vector3_f32(self, name, v):
+        self.ctx.check(lib().tdt_set_vec3f(self.h, name.encode(), float(v[0]), float(v[1]), float(v[2])))
+
+    def set_vector3_i32(self, name, v):
+        self.ctx.check(lib().tdt_set_vec3i(self.h, name.encode(), int(v[0]), int(v[1]), int(v[2])))
+
+
+class ComputeShader:
+    """ComputeShader::new(program) / dispatch_compute(w, h, d) — compute_shader.rs:15-38."""
+
+    def __init__(self, ctx, kind=PROGRAM_RAYTRACER):
+        h = ctypes.c_void_p()
+        ctx.check(lib().tdt_compute_create(ctx.h, kind, ctypes.byref(h)))
+        self.ctx, self.h = ctx, h
+        self.program = Program(ctx, h)
+        gs = (ctypes.c_int * 3)()
+        ctx.check(lib().tdt_compute_group_size(h, gs))
+        self.group_size = list(gs)
+
+    def dispatch_compute(self, width, height, depth):
+        self.ctx.check(lib().tdt_dispatch_compute(self.h, width, height, depth))
+
+    # --- extensions (no reference counterpart) ---
+    def set_partition(self, rank, world):
+        self.ctx.check(lib().tdt_set_partition(self.h, rank, world))
+
+    def dispatch_accumulate(self, width, height, depth, spp_begin, spp_count, carry_ptr=None):
+        self.ctx.check(lib().tdt_dispatch_accumulate(self.h, width, height, depth, spp_begin, spp_count,
+                                                     ctypes.c_void_p(carry_ptr) if carry_ptr else None))
+
+    def dispatch_resolve(self, width, height, depth, total_spp):
+        self.ctx.check(lib().tdt_dispatch_resolve(self.h, width, height, depth, total_spp))
+
+    def covered_pixels(self, width, height, depth=1):
+        return int(lib().tdt_covered_pixels(self.h, width, height, depth))
+
+
+def initial_uniforms(camera, program):
+    """camera.rs:241-253: sends all eight camera uniforms."""
+    program.set_i32("camera.image_width", camera.image_width)
+    program.set_i32("camera.image_height", camera.image_height)
+    program.set_vector3_f32("camera.horizontal", camera.horizontal)
+    program.set_vector3_f32("camera.vertical", camera.vertical)
+    program.set_vector3_f32("camera.lower_left_corner", camera.lower_left_corner)
+    program.set_vector3_f32("camera.origin", camera.origin)
+    program.set_i32("camera.samples_per_pixel", camera.samples_per_pixel)
+    program.set_i32("camera.max_bounce", camera.max_bounce)
+
+
+def upload_scene(ctx, scene):
+    """What main.rs:343-450 and Octree::init_global_buffers (octree.rs:44-100) do: one buffer per
+    payload, bound to its shader-storage slot.  Returns the buffers (keep them alive)."""
+    vbos = {}
+    for slot in (0, 1, 2, 3, 4, 6, 7):
+        vbos[slot] = VertexBufferObject(ctx, scene.blobs[slot])
+        ctx.bind_buffer_base(SHADER_STORAGE_BUFFER, slot, vbos[slot])
+    return vbos
+
+
+class Renderer:
+    """Convenience wrapper used by tests, smoke() and bench.py: a context with one scene, one
+    camera and one image, i.e. the state main.rs has built when it reaches its render loop."""
+
+    def __init__(self, scene, camera, device=0, stream=None, rank=0, world=1, image_ptr=None, image_rows=None):
+        self.ctx = Context(device, stream)
+        self.shader = ComputeShader(self.ctx)
+        self.vbos = upload_scene(self.ctx, scene)
+        self.camera = camera
+        initial_uniforms(camera, self.shader.program)
+        self.shader.set_partition(rank, world)
+        rows = image_rows if image_rows is not None else camera.image_height
+        if image_ptr is not None:
+            self.texture = Texture.wrap_device(self.ctx, image_ptr, camera.image_width, rows)
+        else:
+            self.texture = Texture.new_2d(self.ctx, camera.image_width, rows)
+
+    def dispatch(self, width=None, height=None):
+        """main.rs:579: dispatch_compute(texture.width() + 1, texture.height() + 1, 1)."""
+        w = self.camera.image_width + 1 if width is None else width
+        h = self.camera.image_height + 1 if height is None else height
+        self.shader.dispatch_compute(w, h, 1)
+
+    def render(self, width=None, height=None):
+        self.dispatch(width, height)
+        return self.texture.read()
+
+    def close(self):
+        self.ctx.close()
