@@ -129,19 +129,35 @@ int tdt_image_read(tdt_image *img, float *dst);
 int tdt_dispatch_compute(tdt_compute *c, int width, int height, int depth);
 
 /* ---- extensions with no reference counterpart (documented in DESIGN.md) ------------------ */
-/* Tile partition for one-process-per-GPU rendering: subsequent dispatches of `c` trace only
- * the 32-pixel work-group rows r with r % world == rank.  Default (0,1). */
+/* Tile partition for one-process-per-GPU rendering: the covered image is cut into the
+ * reference's own 32x32 work-groups, numbered row-major t = gy * ceil(cover_w/32) + gx; subsequent
+ * dispatches of `c` trace only the groups with t % world == rank.  Default (0,1).
+ * The bound image is then either the full W x H image (only owned groups are written) or this
+ * rank's TILE BUFFER: an image of width 32 and height 32*n, n >= owned groups, i.e. the owned
+ * groups packed as [k][32][32] RGBA in the order k = 0,1,.. <-> t = rank + k*world. */
 int tdt_set_partition(tdt_compute *c, int rank, int world);
+/* number of groups a dispatch of (width,height,depth) gives this rank; optionally the groups
+ * per row and the total */
+int tdt_owned_tiles(const tdt_compute *c, int width, int height, int depth, int *tiles_x, int *tiles_total);
+/* number of pixels a dispatch of (width,height,depth) writes under the current partition */
+int64_t tdt_covered_pixels(const tdt_compute *c, int width, int height, int depth);
+/* De-interleave gathered tile buffers — `gathered` = device memory [world][tiles_per_rank][32][32]
+ * RGBA as produced by `world` ranks — into the full image `dst` (the step after the RCCL gather). */
+int tdt_assemble_tiles(tdt_compute *c, const void *gathered, int world, int tiles_per_rank, tdt_image *dst,
+                       int width, int height, int depth);
 /* Progressive form of the sample loop: adds samples [spp_begin, spp_begin+spp_count) of every
  * covered pixel, in sample order, to the bound image's rgb running sums (and keeps the
- * shader's loop-carried temporaries in `carry`, W*H*16 floats of device memory, may be NULL
- * on the first pass only if spp_begin == 0 and no further pass follows). */
+ * shader's loop-carried temporaries in `carry`, 16 floats per pixel of the bound image, in
+ * device memory; NULL = start from / discard the initial state). */
 int tdt_dispatch_accumulate(tdt_compute *c, int width, int height, int depth, int spp_begin, int spp_count,
                             void *carry_device_ptr);
 /* image = clamp(sqrt(sum / total_spp), 0, 1), alpha = 1: raytracer.comp:249-251 */
 int tdt_dispatch_resolve(tdt_compute *c, int width, int height, int depth, int total_spp);
-/* number of pixels a dispatch of (width,height,depth) writes under the current partition */
-int64_t tdt_covered_pixels(const tdt_compute *c, int width, int height, int depth);
+/* Instrumented dispatch (measurement only, slower): same image as tdt_dispatch_compute, and
+ * returns event totals: [0] pixels written, [1] OctreeHit calls, [2] traversal iterations,
+ * [3] Node loads (tree levels visited), [4] Lambertian, [5] metal, [6] dielectric scatters,
+ * [7] hits on unknown material types.  Synchronous.  These define the algorithmic bytes. */
+int tdt_dispatch_counted(tdt_compute *c, int width, int height, int depth, uint64_t counts[8]);
 
 #ifdef __cplusplus
 }

@@ -18,72 +18,90 @@
 // ============================================================================ kernels ======
 namespace tdt {
 
-// Pixel owned by this thread.  One wave64 = one 8x8 screen tile; a 256-thread block = a
-// 16x16 pixel quad of tiles.  blockIdx.y walks the 16-pixel half-rows of the 32-pixel
-// work-group rows this rank owns (group row = rank + k*world: SURVEY §8e).
-TDT_DEV bool pixel_of_thread(const TraceParams &P, int &x, int &y, int &img_row) {
+// Pixel owned by this thread.  One wave64 = one 8x8 screen tile; a 256-thread block = a 16x16
+// quad of them; four blocks = one of the reference's 32x32 work-groups.  Work-groups (row-major
+// index t over the covered image) are dealt round-robin to ranks: t % world == rank (SURVEY §8e,
+// refined from group rows to groups for load balance).
+TDT_DEV bool pixel_of_thread(const TraceParams &P, int &x, int &y, size_t &pix) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int k = blockIdx.y >> 1, half = blockIdx.y & 1;
-  const int group_row = P.part_rank + k * P.part_world;
-  x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-  const int in_group = half * 16 + (wave >> 1) * 8 + (lane >> 3);
-  y = group_row * 32 + in_group;
-  img_row = P.compact ? (k * 32 + in_group) : y;
-  return x < P.cover_w && y < P.cover_h && img_row < P.image_rows;
+  const int k = blockIdx.x >> 2, sub = blockIdx.x & 3;
+  const int t = P.part_rank + k * P.part_world;
+  const int gx = t % P.tiles_x, gy = t / P.tiles_x;
+  const int lx = (sub & 1) * 16 + (wave & 1) * 8 + (lane & 7);
+  const int ly = (sub >> 1) * 16 + (wave >> 1) * 8 + (lane >> 3);
+  x = gx * 32 + lx;
+  y = gy * 32 + ly;
+  pix = P.compact ? ((size_t)k * 1024 + (size_t)(ly * 32 + lx)) : ((size_t)y * (size_t)P.image_width + (size_t)x);
+  return x < P.cover_w && y < P.cover_h;
 }
 
-// mode 0: the whole of main() rc:234-252.  mode 1: only the sample loop, adding to running sums.
-template <int MODE>
-__global__ __launch_bounds__(256) void trace_kernel(const TraceParams P) {
-  int x, y, row;
-  if (!pixel_of_thread(P, x, y, row)) return;
-  const size_t pix = (size_t)row * (size_t)P.image_width + (size_t)x;
-  float4 *dst = reinterpret_cast<float4 *>(P.image) + pix;
+TDT_DEV uint32_t wave_sum(uint32_t v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
 
-  Carry pc;
-  pc.root = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}; pc.leaf = pc.root; pc.root_t = 0.f;
-  float sr = 0.f, sg = 0.f, sb = 0.f;
-  if (MODE == 1) {
-    float4 acc = *dst;
-    sr = acc.x; sg = acc.y; sb = acc.z;
-    if (P.carry) {
-      const float4 *c = reinterpret_cast<const float4 *>(P.carry) + pix * 4;
-      float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
-      pc.root = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z != 0.f}; pc.root_t = c1.w;
-      pc.leaf = {c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z != 0.f};
+// MODE 0: the whole of main() rc:234-252.  MODE 1: only the sample loop, adding to running sums.
+// COUNT: instrumented build that also totals the events defining the algorithmic bytes.
+template <int MODE, bool COUNT>
+__global__ __launch_bounds__(256) void trace_kernel(const TraceParams P) {
+  int x, y; size_t pix;
+  const bool active = pixel_of_thread(P, x, y, pix);
+  Counters cnt = {0, 0, 0, 0, 0, 0, 0};
+  if (active) {
+    float4 *dst = reinterpret_cast<float4 *>(P.image) + pix;
+    Carry pc;
+    pc.root = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}; pc.leaf = pc.root; pc.root_t = 0.f;
+    float sr = 0.f, sg = 0.f, sb = 0.f;
+    if (MODE == 1) {
+      float4 acc = *dst;
+      sr = acc.x; sg = acc.y; sb = acc.z;
+      if (P.carry) {
+        const float4 *c = reinterpret_cast<const float4 *>(P.carry) + pix * 4;
+        float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+        pc.root = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z != 0.f}; pc.root_t = c1.w;
+        pc.leaf = {c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z != 0.f};
+      }
+    }
+    const int s_end = P.spp_begin + P.spp_count;
+    for (int s = P.spp_begin; s < s_end; s++) {
+      Ray r = primary_ray(P, x, y, s);
+      float cr, cg, cb;
+      ray_color<COUNT>(P, r, pc, cr, cg, cb, cnt);
+      sr = sr + cr; sg = sg + cg; sb = sb + cb;
+    }
+    if (MODE == 1) {
+      *dst = make_float4(sr, sg, sb, 0.f);
+      if (P.carry) {
+        float4 *c = reinterpret_cast<float4 *>(P.carry) + pix * 4;
+        c[0] = make_float4(pc.root.nx, pc.root.ny, pc.root.nz, pc.root.px);
+        c[1] = make_float4(pc.root.py, pc.root.pz, pc.root.ff ? 1.f : 0.f, pc.root_t);
+        c[2] = make_float4(pc.leaf.nx, pc.leaf.ny, pc.leaf.nz, pc.leaf.px);
+        c[3] = make_float4(pc.leaf.py, pc.leaf.pz, pc.leaf.ff ? 1.f : 0.f, 0.f);
+      }
+    } else {
+      const float n = (float)P.samples_per_pixel;   // rc:249-251
+      float4 o;
+      o.x = f_min(f_max(__builtin_sqrtf(sr / n), 0.f), 1.f);
+      o.y = f_min(f_max(__builtin_sqrtf(sg / n), 0.f), 1.f);
+      o.z = f_min(f_max(__builtin_sqrtf(sb / n), 0.f), 1.f);
+      o.w = 1.0f;
+      *dst = o;
     }
   }
-  const int s_end = P.spp_begin + P.spp_count;
-  for (int s = P.spp_begin; s < s_end; s++) {
-    Ray r = primary_ray(P, x, y, s);
-    float cr, cg, cb;
-    ray_color(P, r, pc, cr, cg, cb);
-    sr = sr + cr; sg = sg + cg; sb = sb + cb;
-  }
-  if (MODE == 1) {
-    *dst = make_float4(sr, sg, sb, 0.f);
-    if (P.carry) {
-      float4 *c = reinterpret_cast<float4 *>(P.carry) + pix * 4;
-      c[0] = make_float4(pc.root.nx, pc.root.ny, pc.root.nz, pc.root.px);
-      c[1] = make_float4(pc.root.py, pc.root.pz, pc.root.ff ? 1.f : 0.f, pc.root_t);
-      c[2] = make_float4(pc.leaf.nx, pc.leaf.ny, pc.leaf.nz, pc.leaf.px);
-      c[3] = make_float4(pc.leaf.py, pc.leaf.pz, pc.leaf.ff ? 1.f : 0.f, 0.f);
+  if (COUNT) {
+    uint32_t v[8] = {active ? 1u : 0u, cnt.octree_hit_calls, cnt.iterations, cnt.node_loads,
+                     cnt.lambertian, cnt.metal, cnt.dielectric, cnt.unknown};
+    for (int i = 0; i < 8; i++) {
+      uint32_t tot = wave_sum(v[i]);
+      if ((threadIdx.x & 63) == 0 && tot) atomicAdd(&P.counters[i], (unsigned long long)tot);
     }
-  } else {
-    const float n = (float)P.samples_per_pixel;   // rc:249-251
-    float4 o;
-    o.x = f_min(f_max(__builtin_sqrtf(sr / n), 0.f), 1.f);
-    o.y = f_min(f_max(__builtin_sqrtf(sg / n), 0.f), 1.f);
-    o.z = f_min(f_max(__builtin_sqrtf(sb / n), 0.f), 1.f);
-    o.w = 1.0f;
-    *dst = o;
   }
 }
 
 __global__ __launch_bounds__(256) void resolve_kernel(const TraceParams P) {
-  int x, y, row;
-  if (!pixel_of_thread(P, x, y, row)) return;
-  float4 *dst = reinterpret_cast<float4 *>(P.image) + ((size_t)row * (size_t)P.image_width + (size_t)x);
+  int x, y; size_t pix;
+  if (!pixel_of_thread(P, x, y, pix)) return;
+  float4 *dst = reinterpret_cast<float4 *>(P.image) + pix;
   float4 a = *dst;
   const float n = (float)P.total_spp;
   float4 o;
@@ -92,6 +110,19 @@ __global__ __launch_bounds__(256) void resolve_kernel(const TraceParams P) {
   o.z = f_min(f_max(__builtin_sqrtf(a.z / n), 0.f), 1.f);
   o.w = 1.0f;
   *dst = o;
+}
+
+// De-interleave gathered per-rank tile buffers ([rank][k][32][32] RGBA) into a W x H image.
+__global__ __launch_bounds__(256) void assemble_kernel(const float4 *__restrict__ tiles, float4 *__restrict__ image,
+                                                       int image_width, int cover_w, int cover_h, int tiles_x,
+                                                       int world, int tiles_per_rank) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= cover_w || y >= cover_h) return;
+  const int t = (y >> 5) * tiles_x + (x >> 5);
+  const int rank = t % world, k = t / world;
+  const size_t src = ((size_t)rank * tiles_per_rank + k) * 1024 + (size_t)((y & 31) * 32 + (x & 31));
+  image[(size_t)y * image_width + x] = tiles[src];
 }
 
 }  // namespace tdt
@@ -124,6 +155,7 @@ struct tdt_ctx {
   tdt_buffer *ssbo[kNumSlots];
   tdt_buffer *atomic0;
   tdt_image *image0;
+  unsigned long long *counters;
   std::vector<tdt_buffer *> buffers;
   std::vector<tdt_image *> images;
   std::vector<tdt_compute *> computes;
@@ -166,23 +198,29 @@ Cover cover_of(const tdt_compute *c, int width, int height) {
   if (k.cover_h < 0) k.cover_h = 0;
   return k;
 }
-// work-group rows this rank owns among ceil(cover_h/32), and the pixel rows they hold
-int owned_group_rows(const tdt_compute *c, int cover_h) {
-  int gy = (cover_h + 31) / 32;
-  return gy > c->part_rank ? (gy - c->part_rank + c->part_world - 1) / c->part_world : 0;
+// 32x32 work-groups of the covered image and the ones this rank owns (t % world == rank)
+struct Tiles { int tiles_x, tiles_y, total, owned; };
+Tiles tiles_of(const tdt_compute *c, const Cover &k) {
+  Tiles t;
+  t.tiles_x = (k.cover_w + 31) / 32; t.tiles_y = (k.cover_h + 31) / 32;
+  t.total = t.tiles_x * t.tiles_y;
+  t.owned = t.total > c->part_rank ? (t.total - c->part_rank + c->part_world - 1) / c->part_world : 0;
+  return t;
 }
-int owned_pixel_rows(const tdt_compute *c, int cover_h) {
-  int n = owned_group_rows(c, cover_h), rows = 0;
-  for (int k = 0; k < n; k++) {
-    int y0 = (c->part_rank + k * c->part_world) * 32;
-    int left = cover_h - y0;
-    rows += left >= 32 ? 32 : (left > 0 ? left : 0);
+int64_t owned_pixels(const tdt_compute *c, const Cover &k) {
+  Tiles t = tiles_of(c, k);
+  int64_t n = 0;
+  for (int i = 0; i < t.owned; i++) {
+    int id = c->part_rank + i * c->part_world;
+    int gx = id % t.tiles_x, gy = id / t.tiles_x;
+    int w = k.cover_w - gx * 32, h = k.cover_h - gy * 32;
+    n += (int64_t)(w > 32 ? 32 : w) * (h > 32 ? 32 : h);
   }
-  return rows;
+  return n;
 }
 
 int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_begin, int spp_count, void *carry,
-           int total_spp) {
+           int total_spp, unsigned long long *counts_out) {
   tdt_ctx *ctx = c->ctx;
   (void)depth;   // raytracer.comp is a 2-D dispatch: groups_z = max(depth / 1, 1) layers all write the same pixels
   static const int required[] = {TDT_SLOT_CELLS, TDT_SLOT_MATERIALS, TDT_SLOT_ALBEDOS, TDT_SLOT_METAL,
@@ -193,8 +231,6 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
   if (ctx->ssbo[TDT_SLOT_OCTREE_FLOATS]->bytes < 28 || ctx->ssbo[TDT_SLOT_OCTREE_INTS]->bytes < 12)
     return fail(ctx, TDT_ERR_INVALID_VALUE, "octree uniform buffers are too small (need 28 / 12 bytes)");
   tdt_image *img = ctx->image0;
-  if (img->w != c->image_width)
-    return fail(ctx, TDT_ERR_INVALID_OPERATION, "bound image width differs from camera.image_width");
 
   TraceParams P;
   std::memset(&P, 0, sizeof P);
@@ -216,22 +252,34 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
   P.dielectric = (const uint32_t *)ctx->ssbo[TDT_SLOT_DIELECTRIC]->dev; P.dielectric_dwords = dwords(ctx->ssbo[TDT_SLOT_DIELECTRIC]);
   P.image = img->dev; P.carry = (float *)carry;
   Cover k = cover_of(c, width, height);
+  Tiles t = tiles_of(c, k);
   P.cover_w = k.cover_w; P.cover_h = k.cover_h;
+  P.tiles_x = t.tiles_x > 0 ? t.tiles_x : 1; P.owned_tiles = t.owned;
   P.part_rank = c->part_rank; P.part_world = c->part_world;
-  const int own_rows = owned_pixel_rows(c, k.cover_h);
-  if (img->h == c->image_height) { P.compact = 0; P.image_rows = img->h; }
-  else if (c->part_world > 1 && img->h >= own_rows) { P.compact = 1; P.image_rows = img->h; }
-  else return fail(ctx, TDT_ERR_INVALID_OPERATION, "bound image height is neither camera.image_height nor this rank's tile rows");
+  if (img->w == c->image_width && img->h == c->image_height) P.compact = 0;
+  else if (img->w == 32 && img->h >= 32 * t.owned && (img->h % 32) == 0) P.compact = 1;   // tile buffer [k][32][32]
+  else return fail(ctx, TDT_ERR_INVALID_OPERATION,
+                   "bound image is neither camera.image_width x image_height nor a 32 x 32*tiles tile buffer");
   P.spp_begin = spp_begin; P.spp_count = spp_count; P.mode = mode; P.total_spp = total_spp;
 
-  const int n_groups = owned_group_rows(c, k.cover_h);
-  if (n_groups <= 0 || k.cover_w <= 0) return TDT_OK;
-  dim3 grid((unsigned)((k.cover_w + 15) / 16), (unsigned)(n_groups * 2), 1), block(256, 1, 1);
   TDT_HIP(ctx, hipSetDevice(ctx->device));
-  if (mode == 0) hipLaunchKernelGGL(tdt::trace_kernel<0>, grid, block, 0, ctx->stream, P);
-  else if (mode == 1) hipLaunchKernelGGL(tdt::trace_kernel<1>, grid, block, 0, ctx->stream, P);
-  else hipLaunchKernelGGL(tdt::resolve_kernel, grid, block, 0, ctx->stream, P);
-  TDT_HIP(ctx, hipGetLastError());
+  if (counts_out) {
+    if (!ctx->counters) TDT_HIP(ctx, hipMalloc((void **)&ctx->counters, 8 * sizeof(unsigned long long)));
+    TDT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    P.counters = ctx->counters;
+  }
+  if (t.owned > 0) {
+    dim3 grid((unsigned)t.owned * 4u, 1, 1), block(256, 1, 1);
+    if (mode == 0 && !counts_out) hipLaunchKernelGGL((tdt::trace_kernel<0, false>), grid, block, 0, ctx->stream, P);
+    else if (mode == 0) hipLaunchKernelGGL((tdt::trace_kernel<0, true>), grid, block, 0, ctx->stream, P);
+    else if (mode == 1) hipLaunchKernelGGL((tdt::trace_kernel<1, false>), grid, block, 0, ctx->stream, P);
+    else hipLaunchKernelGGL(tdt::resolve_kernel, grid, block, 0, ctx->stream, P);
+    TDT_HIP(ctx, hipGetLastError());
+  }
+  if (counts_out) {
+    TDT_HIP(ctx, hipMemcpyAsync(counts_out, ctx->counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    TDT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
   return TDT_OK;
 }
 
@@ -253,7 +301,7 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
   if (!ctx) return fail(nullptr, TDT_ERR_HIP, "out of host memory");
   ctx->device = device_id;
   for (auto &s : ctx->ssbo) s = nullptr;
-  ctx->atomic0 = nullptr; ctx->image0 = nullptr;
+  ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr;
   if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
   else {
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -271,6 +319,7 @@ void tdt_ctx_destroy(tdt_ctx *ctx) {
   for (tdt_compute *c : ctx->computes) delete c;
   for (tdt_buffer *b : ctx->buffers) { (void)hipFree(b->dev); delete b; }
   for (tdt_image *i : ctx->images) { if (i->owned) (void)hipFree(i->dev); delete i; }
+  if (ctx->counters) (void)hipFree(ctx->counters);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -494,7 +543,7 @@ int tdt_image_read(tdt_image *img, float *dst) {
 
 int tdt_dispatch_compute(tdt_compute *c, int width, int height, int depth) {
   if (!c) return TDT_ERR_INVALID_VALUE;
-  return launch(c, width, height, depth, 0, 0, c->samples_per_pixel, nullptr, c->samples_per_pixel);
+  return launch(c, width, height, depth, 0, 0, c->samples_per_pixel, nullptr, c->samples_per_pixel, nullptr);
 }
 
 int tdt_set_partition(tdt_compute *c, int rank, int world) {
@@ -508,19 +557,55 @@ int tdt_dispatch_accumulate(tdt_compute *c, int width, int height, int depth, in
   if (!c) return TDT_ERR_INVALID_VALUE;
   if (spp_begin < 0 || spp_count < 0) return fail(c->ctx, TDT_ERR_INVALID_VALUE, "negative sample range");
   if (carry && ((uintptr_t)carry & 15) != 0) return fail(c->ctx, TDT_ERR_INVALID_VALUE, "carry memory must be 16-byte aligned");
-  return launch(c, width, height, depth, 1, spp_begin, spp_count, carry, 0);
+  return launch(c, width, height, depth, 1, spp_begin, spp_count, carry, 0, nullptr);
 }
 
 int tdt_dispatch_resolve(tdt_compute *c, int width, int height, int depth, int total_spp) {
   if (!c) return TDT_ERR_INVALID_VALUE;
-  return launch(c, width, height, depth, 2, 0, 0, nullptr, total_spp);
+  return launch(c, width, height, depth, 2, 0, 0, nullptr, total_spp, nullptr);
 }
 
 int64_t tdt_covered_pixels(const tdt_compute *c, int width, int height, int depth) {
   (void)depth;
   if (!c) return 0;
+  return owned_pixels(c, cover_of(c, width, height));
+}
+
+int tdt_owned_tiles(const tdt_compute *c, int width, int height, int depth, int *tiles_x, int *tiles_total) {
+  (void)depth;
+  if (!c) return 0;
   Cover k = cover_of(c, width, height);
-  return (int64_t)k.cover_w * owned_pixel_rows(c, k.cover_h);
+  Tiles t = tiles_of(c, k);
+  if (tiles_x) *tiles_x = t.tiles_x;
+  if (tiles_total) *tiles_total = t.total;
+  return t.owned;
+}
+
+int tdt_dispatch_counted(tdt_compute *c, int width, int height, int depth, uint64_t counts[8]) {
+  if (!c || !counts) return TDT_ERR_INVALID_VALUE;
+  static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "");
+  return launch(c, width, height, depth, 0, 0, c->samples_per_pixel, nullptr, c->samples_per_pixel,
+                reinterpret_cast<unsigned long long *>(counts));
+}
+
+int tdt_assemble_tiles(tdt_compute *c, const void *gathered, int world, int tiles_per_rank, tdt_image *dst,
+                       int width, int height, int depth) {
+  (void)depth;
+  if (!c || !gathered || !dst) return TDT_ERR_INVALID_VALUE;
+  tdt_ctx *ctx = c->ctx;
+  if (world < 1 || tiles_per_rank < 0) return fail(ctx, TDT_ERR_INVALID_VALUE, "bad world / tiles_per_rank");
+  if (dst->w != c->image_width || dst->h != c->image_height)
+    return fail(ctx, TDT_ERR_INVALID_OPERATION, "destination image must be camera.image_width x image_height");
+  Cover k = cover_of(c, width, height);
+  if (k.cover_w <= 0 || k.cover_h <= 0) return TDT_OK;
+  const int tiles_x = (k.cover_w + 31) / 32, total = tiles_x * ((k.cover_h + 31) / 32);
+  if ((int64_t)tiles_per_rank * world < total) return fail(ctx, TDT_ERR_INVALID_VALUE, "gathered buffer holds fewer tiles than the image has");
+  TDT_HIP(ctx, hipSetDevice(ctx->device));
+  dim3 grid((unsigned)((k.cover_w + 63) / 64), (unsigned)((k.cover_h + 3) / 4), 1), block(256, 1, 1);
+  hipLaunchKernelGGL(tdt::assemble_kernel, grid, block, 0, ctx->stream, (const float4 *)gathered, (float4 *)dst->dev,
+                     c->image_width, k.cover_w, k.cover_h, tiles_x, world, tiles_per_rank);
+  TDT_HIP(ctx, hipGetLastError());
+  return TDT_OK;
 }
 
 }  // extern "C"

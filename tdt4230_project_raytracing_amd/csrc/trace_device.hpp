@@ -89,6 +89,9 @@ TDT_DEV uint32_t ld_dw(const uint32_t *buf, uint32_t dwords, uint32_t byte_off) 
   return (i < dwords) ? buf[i] : 0u;
 }
 
+// event counts of an instrumented launch (defines the algorithmic bytes)
+struct Counters { uint32_t octree_hit_calls, iterations, node_loads, lambertian, metal, dielectric, unknown; };
+
 struct Ray { float ox, oy, oz, dx, dy, dz; };
 // what one CubeHit call site last produced (rc:336-354); the root and leaf call sites keep
 // theirs across calls, because on a miss the reference's out-parameter copy hands back the
@@ -128,8 +131,9 @@ TDT_DEV void cube_slabs(const Ray &r, float ix, float iy, float iz, float cx, fl
 }
 
 // treeLookup rc:359-394: one dependent 8-byte Node load per level
+template <bool COUNT>
 TDT_DEV bool tree_lookup(const TraceParams &P, float cx, float cy, float cz, float &inv_pow_depth,
-                         float &gx, float &gy, float &gz, uint32_t &value) {
+                         float &gx, float &gy, float &gz, uint32_t &value, Counters &cnt) {
   float ipd = 1.0f, ux = 0.0f, uy = 0.0f, uz = 0.0f;
   uint32_t node_value = 0;
   bool is_leaf = false;
@@ -158,6 +162,7 @@ TDT_DEV bool tree_lookup(const TraceParams &P, float cx, float cy, float cz, flo
       node_value = (dw < P.cells_dwords) ? P.cells[dw] : 0u;
       node_type = 0u;
     }
+    if (COUNT) cnt.node_loads++;
     if (node_type == 0u || node_type == 2u) { is_leaf = (node_type == 2u); break; }
     cx = cx * 2.0f; cy = cy * 2.0f; cz = cz * 2.0f;
   }
@@ -166,8 +171,10 @@ TDT_DEV bool tree_lookup(const TraceParams &P, float cx, float cy, float cz, flo
 }
 
 // OctreeHit rc:397-450 with t_min = 0.0003, t_max = +inf (rc:271)
-TDT_DEV bool octree_hit(const TraceParams &P, const Ray &r, Carry &pc, Hit &hit) {
+template <bool COUNT>
+TDT_DEV bool octree_hit(const TraceParams &P, const Ray &r, Carry &pc, Hit &hit, Counters &cnt) {
   const float inf = __builtin_inff();
+  if (COUNT) cnt.octree_hit_calls++;
   float ix = f_rcp(r.dx), iy = f_rcp(r.dy), iz = f_rcp(r.dz);
   float t_enter, t_exit;
   {
@@ -197,7 +204,8 @@ TDT_DEV bool octree_hit(const TraceParams &P, const Ray &r, Carry &pc, Hit &hit)
       if ((__builtin_fabsf(ez) + __builtin_fabsf(ey)) != -__builtin_fabsf(ex)) return false;
     }
     float gx, gy, gz; uint32_t value;
-    bool leaf = tree_lookup(P, lx, ly, lz, inv_pow_depth, gx, gy, gz, value);
+    if (COUNT) cnt.iterations++;
+    bool leaf = tree_lookup<COUNT>(P, lx, ly, lz, inv_pow_depth, gx, gy, gz, value, cnt);
     if (leaf) {
       if (i > 0) {
         float cx = gx * P.scale + P.min_x, cy = gy * P.scale + P.min_y, cz = gz * P.scale + P.min_z;
@@ -232,12 +240,14 @@ TDT_DEV void load_albedo(const TraceParams &P, uint32_t mo, float &ar, float &ag
 }
 
 // switch (materials[hit.index].type) rc:278-291; returns false when the path ends
-TDT_DEV bool scatter(const TraceParams &P, const Ray &r, const Hit &h, Ray &out, float &ar, float &ag, float &ab) {
+template <bool COUNT>
+TDT_DEV bool scatter(const TraceParams &P, const Ray &r, const Hit &h, Ray &out, float &ar, float &ag, float &ab, Counters &cnt) {
   uint32_t mo = h.index * 12u;
   int32_t type = (int32_t)ld_dw(P.materials, P.materials_dwords, mo);
   float dx = r.dx, dy = r.dy, dz = r.dz;
   float nx = h.nx, ny = h.ny, nz = h.nz;
   out.ox = h.px; out.oy = h.py; out.oz = h.pz;
+  if (COUNT) { cnt.lambertian += (type == 0); cnt.metal += (type == 1); cnt.dielectric += (type == 2); cnt.unknown += ((uint32_t)type > 2u); }
   if (type == 0) {   // ScatterLambertian rc:470-482, constructFrisvad rc:453-468, SampleGGXVNDF rc:27-49
     float rs = f_rsq((nz * nz + ny * ny) + nx * nx);
     float mx = nx * rs, my = ny * rs, mz = nz * rs;
@@ -366,14 +376,15 @@ TDT_DEV Ray primary_ray(const TraceParams &P, int px, int py, int s) {
 }
 
 // RayColor rc:264-302
-TDT_DEV void ray_color(const TraceParams &P, Ray r, Carry &pc, float &cr, float &cg, float &cb) {
+template <bool COUNT>
+TDT_DEV void ray_color(const TraceParams &P, Ray r, Carry &pc, float &cr, float &cg, float &cb, Counters &cnt) {
   float ar = 1.0f, ag = 1.0f, ab = 1.0f;
   int32_t loop_count = 0;
   Hit h;
-  while (loop_count < P.max_bounce && octree_hit(P, r, pc, h)) {
+  while (loop_count < P.max_bounce && octree_hit<COUNT>(P, r, pc, h, cnt)) {
     loop_count += 1;
     Ray nr; float tr, tg, tb;
-    if (!scatter(P, r, h, nr, tr, tg, tb)) break;
+    if (!scatter<COUNT>(P, r, h, nr, tr, tg, tb, cnt)) break;
     ar = ar * tr; ag = ag * tg; ab = ab * tb;
     r = nr;
   }

@@ -20,10 +20,12 @@ struct TraceParams {
   // output image (RGBA32F, row 0 = bottom) and optional per-pixel carry (16 floats / pixel)
   float *image;
   float *carry;
-  int32_t image_rows;          // rows the bound image really has (full height, or compact tile rows)
-  int32_t compact;             // 1: image holds only this rank's work-group rows, packed
+  unsigned long long *counters; // instrumented launches only: 8 event totals (see Counters)
+  int32_t compact;             // 1: image is this rank's tile buffer [owned tile k][32][32] RGBA
   int32_t cover_w, cover_h;    // pixels a dispatch covers: min(32*groups, image size)
-  int32_t part_rank, part_world;  // work-group-row partition (r % world == rank)
+  int32_t tiles_x;             // 32x32 work-groups per row = ceil(cover_w / 32)
+  int32_t owned_tiles;         // work-groups this rank traces
+  int32_t part_rank, part_world;  // work-group partition: tile t (row-major) belongs to rank t % world
   int32_t spp_begin, spp_count;   // sample range of this launch
   int32_t mode;                // 0 render (sum, sqrt, clamp, store), 1 accumulate into image, 2 resolve
   int32_t total_spp;           // resolve divisor

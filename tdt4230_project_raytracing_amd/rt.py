@@ -55,6 +55,9 @@ SYMBOLS = [
     ("tdt_dispatch_accumulate", _I, [_P, _I, _I, _I, _I, _I, _P]),
     ("tdt_dispatch_resolve", _I, [_P, _I, _I, _I, _I]),
     ("tdt_covered_pixels", ctypes.c_int64, [_P, _I, _I, _I]),
+    ("tdt_owned_tiles", _I, [_P, _I, _I, _I, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    ("tdt_assemble_tiles", _I, [_P, _P, _I, _I, _P, _I, _I, _I]),
+    ("tdt_dispatch_counted", _I, [_P, _I, _I, _I, ctypes.POINTER(ctypes.c_uint64)]),
 ]
 
 _lib = None
@@ -222,6 +225,25 @@ class ComputeShader:
     def covered_pixels(self, width, height, depth=1):
         return int(lib().tdt_covered_pixels(self.h, width, height, depth))
 
+    def owned_tiles(self, width, height, depth=1):
+        """(owned, tiles_per_row, total) 32x32 work-groups of a dispatch under the current partition."""
+        tx, tot = ctypes.c_int(), ctypes.c_int()
+        n = lib().tdt_owned_tiles(self.h, width, height, depth, ctypes.byref(tx), ctypes.byref(tot))
+        return int(n), tx.value, tot.value
+
+    def assemble_tiles(self, gathered_ptr, world, tiles_per_rank, dst_texture, width, height, depth=1):
+        self.ctx.check(lib().tdt_assemble_tiles(self.h, ctypes.c_void_p(gathered_ptr), world, tiles_per_rank,
+                                                dst_texture.h, width, height, depth))
+
+    COUNT_FIELDS = ("pixels", "octree_hit_calls", "iterations", "node_loads", "lambertian", "metal", "dielectric",
+                    "unknown_material")
+
+    def dispatch_counted(self, width, height, depth=1):
+        """Instrumented dispatch: event totals that define the algorithmic bytes."""
+        c = (ctypes.c_uint64 * 8)()
+        self.ctx.check(lib().tdt_dispatch_counted(self.h, width, height, depth, c))
+        return dict(zip(self.COUNT_FIELDS, [int(v) for v in c]))
+
 
 def initial_uniforms(camera, program):
     """camera.rs:241-253: sends all eight camera uniforms."""
@@ -249,18 +271,21 @@ class Renderer:
     """Convenience wrapper used by tests, smoke() and bench.py: a context with one scene, one
     camera and one image, i.e. the state main.rs has built when it reaches its render loop."""
 
-    def __init__(self, scene, camera, device=0, stream=None, rank=0, world=1, image_ptr=None, image_rows=None):
+    def __init__(self, scene, camera, device=0, stream=None, rank=0, world=1, image_ptr=None, tile_buffer_tiles=None):
         self.ctx = Context(device, stream)
         self.shader = ComputeShader(self.ctx)
         self.vbos = upload_scene(self.ctx, scene)
         self.camera = camera
         initial_uniforms(camera, self.shader.program)
         self.shader.set_partition(rank, world)
-        rows = image_rows if image_rows is not None else camera.image_height
-        if image_ptr is not None:
-            self.texture = Texture.wrap_device(self.ctx, image_ptr, camera.image_width, rows)
+        if tile_buffer_tiles is not None:      # this rank's tile buffer [k][32][32] RGBA
+            w, rows = 32, 32 * tile_buffer_tiles
         else:
-            self.texture = Texture.new_2d(self.ctx, camera.image_width, rows)
+            w, rows = camera.image_width, camera.image_height
+        if image_ptr is not None:
+            self.texture = Texture.wrap_device(self.ctx, image_ptr, w, rows)
+        else:
+            self.texture = Texture.new_2d(self.ctx, w, rows)
 
     def dispatch(self, width=None, height=None):
         """main.rs:579: dispatch_compute(texture.width() + 1, texture.height() + 1, 1)."""
