@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -15,24 +16,42 @@
 #include "trace_device.hpp"
 #include "trace_params.h"
 
+#ifndef TDT_MIN_WAVES
+#define TDT_MIN_WAVES 4
+#endif
+#ifndef TDT_EVENT_THRESHOLD
+#define TDT_EVENT_THRESHOLD 24   // lanes that must wait for scatter / new-sample code before a wave runs it
+#endif
+
 // ============================================================================ kernels ======
 namespace tdt {
 
-// Pixel owned by this thread.  One wave64 = one 8x8 screen tile; a 256-thread block = a 16x16
-// quad of them; four blocks = one of the reference's 32x32 work-groups.  Work-groups (row-major
-// index t over the covered image) are dealt round-robin to ranks: t % world == rank (SURVEY §8e,
-// refined from group rows to groups for load balance).
-TDT_DEV bool pixel_of_thread(const TraceParams &P, int &x, int &y, size_t &pix) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int k = blockIdx.x >> 2, sub = blockIdx.x & 3;
-  const int t = P.part_rank + k * P.part_world;
-  const int gx = t % P.tiles_x, gy = t / P.tiles_x;
-  const int lx = (sub & 1) * 16 + (wave & 1) * 8 + (lane & 7);
-  const int ly = (sub >> 1) * 16 + (wave >> 1) * 8 + (lane >> 3);
+// ---- work decomposition ------------------------------------------------------------------
+// One 256-thread block (4 wave64) owns one of the reference's 32x32 work-groups (row-major index
+// t over the covered image; t % world == rank picks this rank's groups: SURVEY §8e).  Its 1024
+// pixels are NOT bound to threads: lanes are persistent and pull the next pixel from a
+// block-local queue (one LDS counter, advanced once per wave by ballot + prefix count) whenever
+// they finish all samples of their current one, so a lane that drew cheap (sky) pixels keeps
+// working instead of idling behind the most expensive pixel of its tile.  The queue hands pixels
+// out tile-major (8x8), so the lanes of a wave stay on neighbouring pixels and share octree
+// nodes / cache lines.
+TDT_DEV void decode_pixel(const TraceParams &P, int gx, int gy, int k, uint32_t p, int &x, int &y, size_t &pix, bool &inside) {
+  const int tile = (int)(p >> 6), w = (int)(p & 63);
+  const int lx = (tile & 3) * 8 + (w & 7), ly = (tile >> 2) * 8 + (w >> 3);
   x = gx * 32 + lx;
   y = gy * 32 + ly;
   pix = P.compact ? ((size_t)k * 1024 + (size_t)(ly * 32 + lx)) : ((size_t)y * (size_t)P.image_width + (size_t)x);
-  return x < P.cover_w && y < P.cover_h;
+  inside = x < P.cover_w && y < P.cover_h;
+}
+
+// pixel addressing of the one-thread-per-pixel helper kernels (resolve)
+TDT_DEV bool pixel_of_thread(const TraceParams &P, int &x, int &y, size_t &pix) {
+  const int k = blockIdx.x >> 2, sub = blockIdx.x & 3;
+  const int t = P.part_rank + k * P.part_world;
+  const int gx = t % P.tiles_x, gy = t / P.tiles_x;
+  bool inside;
+  decode_pixel(P, gx, gy, k, (uint32_t)(sub * 256 + threadIdx.x), x, y, pix, inside);
+  return inside;
 }
 
 TDT_DEV uint32_t wave_sum(uint32_t v) {
@@ -40,56 +59,218 @@ TDT_DEV uint32_t wave_sum(uint32_t v) {
   return v;
 }
 
+// Lane states of the flattened path tracer.  The reference's loop nest
+//   for sample { while bounce { for traversal-step { for level } } }        (rc:238,271,410,372)
+// is run per lane as a state machine, so lanes of one wave can be in different samples /
+// bounces / steps at the same time; every lane still executes exactly the reference's sequence
+// of operations for its own pixel, in the same order (bit-identical sums).
+enum : int { ST_TRAVERSE = 0, ST_HIT = 1, ST_END = 2, ST_FETCH = 3, ST_PRIMARY = 4, ST_NEWRAY = 5, ST_DONE = 6 };
+
 // MODE 0: the whole of main() rc:234-252.  MODE 1: only the sample loop, adding to running sums.
 // COUNT: instrumented build that also totals the events defining the algorithmic bytes.
-template <int MODE, bool COUNT>
-__global__ __launch_bounds__(256) void trace_kernel(const TraceParams P) {
-  int x, y; size_t pix;
-  const bool active = pixel_of_thread(P, x, y, pix);
+// POW2: exact-comparison treeLookup (see tree_lookup_pow2) vs the literal float form.
+template <int MODE, bool COUNT, bool POW2>
+__global__ __launch_bounds__(256, TDT_MIN_WAVES) void trace_kernel(const TraceParams P) {
+  __shared__ uint32_t s_next_pixel;
+  const int k = blockIdx.x;
+  const int t = P.part_rank + k * P.part_world;
+  const int gx = t % P.tiles_x, gy = t / P.tiles_x;
+  if (threadIdx.x == 0) s_next_pixel = 0;
+  __syncthreads();
+
+  const float inf = __builtin_inff();
   Counters cnt = {0, 0, 0, 0, 0, 0, 0};
-  if (active) {
-    float4 *dst = reinterpret_cast<float4 *>(P.image) + pix;
-    Carry pc;
-    pc.root = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}; pc.leaf = pc.root; pc.root_t = 0.f;
-    float sr = 0.f, sg = 0.f, sb = 0.f;
-    if (MODE == 1) {
-      float4 acc = *dst;
-      sr = acc.x; sg = acc.y; sb = acc.z;
-      if (P.carry) {
-        const float4 *c = reinterpret_cast<const float4 *>(P.carry) + pix * 4;
-        float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
-        pc.root = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z != 0.f}; pc.root_t = c1.w;
-        pc.leaf = {c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z != 0.f};
+  uint32_t n_pixels = 0;
+  NodeMemo<kMemoLevels> memo;
+#pragma unroll
+  for (int l = 0; l < kMemoLevels; l++) { memo.key[l] = 0x3FFFFFFFu; memo.val[l] = 0u; }
+
+  int state = ST_FETCH;
+  int x = 0, y = 0; size_t pix = 0;
+  int s = 0, loop_count = 0;
+  Ray r = {0.f, 0.f, 0.f, 0.f, 0.f, 1.f};
+  float ix = 0.f, iy = 0.f, iz = 0.f;                // 1 / direction (ray-invariant, rc:319)
+  float ar = 1.f, ag = 1.f, ab = 1.f;                // accumulative_attenuation rc:267
+  float sr = 0.f, sg = 0.f, sb = 0.f;                // color rc:237
+  float t_stride = 0.f, t_octree_max = 0.f, inv_pow_depth = 0.5f;
+  int it = 0;                                        // OctreeHit's i rc:410
+  bool use_leaf = false; uint32_t hit_index = 0;
+  Carry pc;
+  pc.root = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}; pc.leaf = pc.root; pc.root_t = 0.f;
+  const int s_end = P.spp_begin + P.spp_count;
+
+  for (;;) {
+    // ------------------------------------------------------------ one traversal step rc:410-447
+    if (state == ST_TRAVERSE) {
+      if (!(it < P.max_iter && t_stride < t_octree_max)) {
+        state = ST_END;                               // OctreeHit returns false rc:449
+      } else {
+        const float adv = f_max(0.0001f * (inv_pow_depth + 0.1f), 0.000001f);
+        const float tt = t_stride + adv;
+        const float wx = tt * r.dx + r.ox, wy = tt * r.dy + r.oy, wz = tt * r.dz + r.oz;
+        const float lx = (wx + -P.min_x) * P.inv_scale, ly = (wy + -P.min_y) * P.inv_scale, lz = (wz + -P.min_z) * P.inv_scale;
+        bool outside;
+        if (POW2) {
+          // rc:417 "fract(p) - p != vec3(0)": fract(p) - p is zero exactly for p in [0,1) (and -0)
+          outside = !((lx >= 0.0f) & (lx < 1.0f) & (ly >= 0.0f) & (ly < 1.0f) & (lz >= 0.0f) & (lz < 1.0f));
+        } else {
+          const float ex = f_fract(lx) + -lx, ey = f_fract(ly) + -ly, ez = f_fract(lz) + -lz;
+          outside = (__builtin_fabsf(ez) + __builtin_fabsf(ey)) != -__builtin_fabsf(ex);
+        }
+        if (outside) {
+          state = ST_END;
+        } else {
+          float ugx, ugy, ugz; uint32_t value;
+          if (COUNT) cnt.iterations++;
+          const bool leaf = POW2 ? tree_lookup_pow2<COUNT, kMemoLevels>(P, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, memo, cnt)
+                                 : tree_lookup<COUNT>(P, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, cnt);
+          const float bx = ugx * P.scale + P.min_x, by = ugy * P.scale + P.min_y, bz = ugz * P.scale + P.min_z;
+          const float cs0 = P.scale * inv_pow_depth;
+          // leaf: the exact cell (rc:427-428); empty: padded by -1e-5 / +2e-5 (rc:441-442)
+          const float cx = leaf ? bx : bx + -0.00001f, cy = leaf ? by : by + -0.00001f, cz = leaf ? bz : bz + -0.00001f;
+          const float cs = leaf ? cs0 : cs0 + 0.00002f;
+          float t_enter, t_exit;
+          cube_slabs(r, ix, iy, iz, cx, cy, cz, cs, t_stride, t_octree_max, t_enter, t_exit);
+          const bool cube_ok = !(t_exit < t_enter);
+          if (leaf) {
+            if (it > 0 && cube_ok) cube_hit_record(r, t_enter, cx, cy, cz, cs, pc.leaf);
+            use_leaf = it > 0; hit_index = value;
+            state = ST_HIT;
+          } else {
+            t_stride = cube_ok ? t_exit : t_octree_max;
+            it++;
+          }
+        }
       }
     }
-    const int s_end = P.spp_begin + P.spp_count;
-    for (int s = P.spp_begin; s < s_end; s++) {
-      Ray r = primary_ray(P, x, y, s);
+
+    // ------------------------------------------------------------ path events
+    const unsigned long long m_trav = __ballot(state == ST_TRAVERSE);
+    const unsigned long long m_event = __ballot(state != ST_TRAVERSE && state != ST_DONE);
+    if (m_trav == 0ull && m_event == 0ull) break;
+    // run the (long, material-divergent) event code only when enough lanes wait for it
+    if (__popcll(m_event) < TDT_EVENT_THRESHOLD && m_trav != 0ull) continue;
+
+    if (state == ST_HIT) {                            // RayColor loop body rc:272-295
+      loop_count += 1;
+      const HitTmp &src = use_leaf ? pc.leaf : pc.root;
+      Hit h;
+      h.px = src.px; h.py = src.py; h.pz = src.pz; h.nx = src.nx; h.ny = src.ny; h.nz = src.nz; h.ff = src.ff;
+      h.index = hit_index;
+      Ray nr; float tr, tg, tb;
+      if (scatter<COUNT>(P, r, h, nr, tr, tg, tb, cnt)) {
+        ar = ar * tr; ag = ag * tg; ab = ab * tb;
+        r = nr;
+        state = ST_NEWRAY;
+      } else {
+        state = ST_END;
+      }
+    }
+    if (state == ST_END) {                            // rc:297-301, rc:246
       float cr, cg, cb;
-      ray_color<COUNT>(P, r, pc, cr, cg, cb, cnt);
-      sr = sr + cr; sg = sg + cg; sb = sb + cb;
-    }
-    if (MODE == 1) {
-      *dst = make_float4(sr, sg, sb, 0.f);
-      if (P.carry) {
-        float4 *c = reinterpret_cast<float4 *>(P.carry) + pix * 4;
-        c[0] = make_float4(pc.root.nx, pc.root.ny, pc.root.nz, pc.root.px);
-        c[1] = make_float4(pc.root.py, pc.root.pz, pc.root.ff ? 1.f : 0.f, pc.root_t);
-        c[2] = make_float4(pc.leaf.nx, pc.leaf.ny, pc.leaf.nz, pc.leaf.px);
-        c[3] = make_float4(pc.leaf.py, pc.leaf.pz, pc.leaf.ff ? 1.f : 0.f, 0.f);
+      if (loop_count > 0) { cr = ar; cg = ag; cb = ab; }
+      else {
+        const float yp = r.dy + 1.0f;
+        const float w = 1.0f + -(0.5f * yp);
+        cr = w + 0.25f * yp; cg = w + 0.35f * yp; cb = 1.0f;
       }
-    } else {
-      const float n = (float)P.samples_per_pixel;   // rc:249-251
-      float4 o;
-      o.x = f_min(f_max(__builtin_sqrtf(sr / n), 0.f), 1.f);
-      o.y = f_min(f_max(__builtin_sqrtf(sg / n), 0.f), 1.f);
-      o.z = f_min(f_max(__builtin_sqrtf(sb / n), 0.f), 1.f);
-      o.w = 1.0f;
-      *dst = o;
+      sr = sr + cr; sg = sg + cg; sb = sb + cb;
+      s++;
+      if (s < s_end) state = ST_PRIMARY;
+      else {
+        float4 *dst = reinterpret_cast<float4 *>(P.image) + pix;
+        if (MODE == 1) {
+          *dst = make_float4(sr, sg, sb, 0.f);
+          if (P.carry) {
+            float4 *c = reinterpret_cast<float4 *>(P.carry) + pix * 4;
+            c[0] = make_float4(pc.root.nx, pc.root.ny, pc.root.nz, pc.root.px);
+            c[1] = make_float4(pc.root.py, pc.root.pz, pc.root.ff ? 1.f : 0.f, pc.root_t);
+            c[2] = make_float4(pc.leaf.nx, pc.leaf.ny, pc.leaf.nz, pc.leaf.px);
+            c[3] = make_float4(pc.leaf.py, pc.leaf.pz, pc.leaf.ff ? 1.f : 0.f, 0.f);
+          }
+        } else {
+          const float n = (float)P.samples_per_pixel;   // rc:249-251
+          float4 o;
+          o.x = f_min(f_max(__builtin_sqrtf(sr / n), 0.f), 1.f);
+          o.y = f_min(f_max(__builtin_sqrtf(sg / n), 0.f), 1.f);
+          o.z = f_min(f_max(__builtin_sqrtf(sb / n), 0.f), 1.f);
+          o.w = 1.0f;
+          *dst = o;
+        }
+        state = ST_FETCH;
+      }
+    }
+    {                                                 // next pixel from the block queue
+      const bool want = state == ST_FETCH;
+      const unsigned long long m = __ballot(want);
+      if (m != 0ull) {
+        uint32_t base = 0;
+        if ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&s_next_pixel, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, __builtin_ctzll(m), 64);
+        if (want) {
+          const uint32_t p = base + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+          if (p >= 1024u) state = ST_DONE;
+          else {
+            bool inside;
+            decode_pixel(P, gx, gy, k, p, x, y, pix, inside);
+            if (inside) {                             // outside the covered image: ask again next time
+              n_pixels++;
+              sr = 0.f; sg = 0.f; sb = 0.f; s = P.spp_begin;
+              pc.root = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}; pc.leaf = pc.root; pc.root_t = 0.f;
+              if (MODE == 1) {
+                const float4 acc = *(reinterpret_cast<const float4 *>(P.image) + pix);
+                sr = acc.x; sg = acc.y; sb = acc.z;
+                if (P.carry) {
+                  const float4 *c = reinterpret_cast<const float4 *>(P.carry) + pix * 4;
+                  const float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+                  pc.root = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z != 0.f}; pc.root_t = c1.w;
+                  pc.leaf = {c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z != 0.f};
+                }
+              }
+              if (s < s_end) state = ST_PRIMARY;
+              else if (MODE == 0) {                   // zero samples: main() still stores sqrt(0/0) clamped
+                const float n = (float)P.samples_per_pixel;
+                const float v0 = f_min(f_max(__builtin_sqrtf(0.f / n), 0.f), 1.f);
+                *(reinterpret_cast<float4 *>(P.image) + pix) = make_float4(v0, v0, v0, 1.0f);
+              }
+            }
+          }
+        }
+      }
+    }
+    if (state == ST_PRIMARY) {                        // rc:240-245
+      r = primary_ray(P, x, y, s);
+      loop_count = 0; ar = 1.f; ag = 1.f; ab = 1.f;
+      state = ST_NEWRAY;
+    }
+    if (state == ST_NEWRAY) {                         // while-condition rc:271 + OctreeHit prologue rc:399-408
+      if (!(loop_count < P.max_bounce)) state = ST_END;
+      else {
+        if (COUNT) cnt.octree_hit_calls++;
+        ix = f_rcp(r.dx); iy = f_rcp(r.dy); iz = f_rcp(r.dz);
+        const float lx = (P.min_x + -r.ox) * ix, ly = (P.min_y + -r.oy) * iy, lz = (P.min_z + -r.oz) * iz;
+        const float ux = ((P.min_x + P.scale) + -r.ox) * ix, uy = ((P.min_y + P.scale) + -r.oy) * iy,
+                    uz = ((P.min_z + P.scale) + -r.oz) * iz;
+        const float mnx = f_min(lx, ux), mny = f_min(ly, uy), mnz = f_min(lz, uz);
+        const float mxx = f_max(lx, ux), mxy = f_max(ly, uy), mxz = f_max(lz, uz);
+        const float t_enter = f_max(f_max(f_max(mnx, 0.0003f), mny), mnz);
+        const float t_exit = f_min(f_min(f_min(mxx, inf), mxy), mxz);
+        t_octree_max = inf;
+        if (t_exit >= t_enter) {
+          cube_hit_record(r, t_enter, P.min_x, P.min_y, P.min_z, P.scale, pc.root);
+          pc.root_t = t_enter;
+          t_octree_max = t_exit;
+        }
+        t_stride = pc.root_t;
+        inv_pow_depth = 0.5f;
+        it = 0;
+        state = ST_TRAVERSE;
+      }
     }
   }
+
   if (COUNT) {
-    uint32_t v[8] = {active ? 1u : 0u, cnt.octree_hit_calls, cnt.iterations, cnt.node_loads,
+    uint32_t v[8] = {n_pixels, cnt.octree_hit_calls, cnt.iterations, cnt.node_loads,
                      cnt.lambertian, cnt.metal, cnt.dielectric, cnt.unknown};
     for (int i = 0; i < 8; i++) {
       uint32_t tot = wave_sum(v[i]);
@@ -156,6 +337,7 @@ struct tdt_ctx {
   tdt_buffer *atomic0;
   tdt_image *image0;
   unsigned long long *counters;
+  bool force_generic;   // TDT_FORCE_GENERIC=1: always run the literal-arithmetic kernel (A/B testing)
   std::vector<tdt_buffer *> buffers;
   std::vector<tdt_image *> images;
   std::vector<tdt_compute *> computes;
@@ -269,11 +451,20 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     P.counters = ctx->counters;
   }
   if (t.owned > 0) {
-    dim3 grid((unsigned)t.owned * 4u, 1, 1), block(256, 1, 1);
-    if (mode == 0 && !counts_out) hipLaunchKernelGGL((tdt::trace_kernel<0, false>), grid, block, 0, ctx->stream, P);
-    else if (mode == 0) hipLaunchKernelGGL((tdt::trace_kernel<0, true>), grid, block, 0, ctx->stream, P);
-    else if (mode == 1) hipLaunchKernelGGL((tdt::trace_kernel<1, false>), grid, block, 0, ctx->stream, P);
-    else hipLaunchKernelGGL(tdt::resolve_kernel, grid, block, 0, ctx->stream, P);
+    dim3 grid((unsigned)t.owned, 1, 1), grid4((unsigned)t.owned * 4u, 1, 1), block(256, 1, 1);
+    // the exact-comparison form of treeLookup needs cell_count = 2^k <= 2^22 and inv_cell_count = 2^-k
+    // bit-for-bit (true for every scene Octree::init_global_buffers builds from such a count,
+    // octree.rs:49); anything else (e.g. the demo scene's 100000) takes the literal float form
+    const uint32_t cc = (uint32_t)P.cell_count;
+    const bool pow2 = !ctx->force_generic && P.cell_count > 0 && (cc & (cc - 1)) == 0 && cc <= (1u << 22) &&
+                      P.inv_cell_count == 1.0f / (float)cc && P.max_depth <= 32;
+#define TDT_LAUNCH(M, C) do { if (pow2) hipLaunchKernelGGL((tdt::trace_kernel<M, C, true>), grid, block, 0, ctx->stream, P); \
+                              else hipLaunchKernelGGL((tdt::trace_kernel<M, C, false>), grid, block, 0, ctx->stream, P); } while (0)
+    if (mode == 0 && !counts_out) TDT_LAUNCH(0, false);
+    else if (mode == 0) TDT_LAUNCH(0, true);
+    else if (mode == 1) TDT_LAUNCH(1, false);
+    else hipLaunchKernelGGL(tdt::resolve_kernel, grid4, block, 0, ctx->stream, P);
+#undef TDT_LAUNCH
     TDT_HIP(ctx, hipGetLastError());
   }
   if (counts_out) {
@@ -302,6 +493,7 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
   ctx->device = device_id;
   for (auto &s : ctx->ssbo) s = nullptr;
   ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr;
+  { const char *fg = getenv("TDT_FORCE_GENERIC"); ctx->force_generic = fg && fg[0] == '1'; }
   if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
   else {
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);

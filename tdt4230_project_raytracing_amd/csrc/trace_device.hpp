@@ -22,6 +22,11 @@ TDT_DEV float f_rsq(float x) { return 1.0f / __builtin_sqrtf(x); }          // t
 // min/max where a NaN operand yields the other operand (and ties return b)
 TDT_DEV float f_min(float a, float b) { return (b != b) ? a : (a < b ? a : b); }
 TDT_DEV float f_max(float a, float b) { return (b != b) ? a : (a > b ? a : b); }
+// v_min_f32 / v_max_f32 (IEEE minNum / maxNum): identical to f_min / f_max except for which
+// zero a (+0,-0) tie returns — which no consumer below can observe (the slab chains only
+// compare these values, or use them when they are strictly positive)
+TDT_DEV float hw_min(float a, float b) { return __builtin_fminf(a, b); }
+TDT_DEV float hw_max(float a, float b) { return __builtin_fmaxf(a, b); }
 TDT_DEV float b2f(bool b) { return b ? 1.0f : 0.0f; }
 TDT_DEV int32_t f2i(float f) {   // truncating convert; out of range / NaN -> INT_MIN
   return (f > -2147483904.0f && f < 2147483648.0f) ? (int32_t)f : (int32_t)0x80000000;
@@ -124,10 +129,10 @@ TDT_DEV void cube_slabs(const Ray &r, float ix, float iy, float iz, float cx, fl
                         float t_min, float t_max, float &t_enter, float &t_exit) {
   float lx = (cx + -r.ox) * ix, ly = (cy + -r.oy) * iy, lz = (cz + -r.oz) * iz;
   float ux = ((cx + size) + -r.ox) * ix, uy = ((cy + size) + -r.oy) * iy, uz = ((cz + size) + -r.oz) * iz;
-  float mnx = f_min(lx, ux), mny = f_min(ly, uy), mnz = f_min(lz, uz);
-  float mxx = f_max(lx, ux), mxy = f_max(ly, uy), mxz = f_max(lz, uz);
-  t_enter = f_max(f_max(f_max(t_min, mnx), mny), mnz);
-  t_exit = f_min(f_min(f_min(t_max, mxx), mxy), mxz);
+  float mnx = hw_min(lx, ux), mny = hw_min(ly, uy), mnz = hw_min(lz, uz);
+  float mxx = hw_max(lx, ux), mxy = hw_max(ly, uy), mxz = hw_max(lz, uz);
+  t_enter = hw_max(hw_max(hw_max(t_min, mnx), mny), mnz);
+  t_exit = hw_min(hw_min(hw_min(t_max, mxx), mxy), mxz);
 }
 
 // treeLookup rc:359-394: one dependent 8-byte Node load per level
@@ -170,9 +175,88 @@ TDT_DEV bool tree_lookup(const TraceParams &P, float cx, float cy, float cz, flo
   return is_leaf;
 }
 
+// Per-lane memo of the last node fetched at each of the first CL levels.  The scene is
+// read-only, so "node idx at level l" fetched for the previous traversal step is still the
+// node: consecutive steps of a ray (and consecutive rays of a pixel) share most of their root
+// path, which turns the reference's restart-from-root into ~1 dependent load per step without
+// changing a single decision.  key = node index (29 bits) | type code << 30.
+template <int CL>
+struct NodeMemo { uint32_t key[CL]; uint32_t val[CL]; };
+constexpr int kMemoLevels = 9;
+
+// treeLookup rc:359-394 specialised for cell_count = 2^k <= 2^22 with inv_cell_count = 2^-k
+// (checked on the host), where the float index arithmetic collapses to exact comparisons:
+//   y,z: round_even(f*2 - 0.5) = (f > 0.5)                       [f in [0,1)]
+//   x  : ((v + fx) * 2^-k) * 2^(k+1) - 0.5 = 2*s - 0.5 exactly, s = fl(float(v) + fx); with
+//        q = s - float(v) (exact) round_even gives 2v + (q > 0.5) + (q == 1): the second term is
+//        the reference's own rounding artefact (fx rounded up to 1.0 at large v lands in the
+//        NEXT cell), kept.  Needs v < 2^22 so that 2s - 0.5 is exact; larger v takes the
+//        literal formula.
+// Coordinates: the reference recomputes fract(c * 2^l) per level; fract(2 f) is the same number
+// (all exact), and c in [0,1) on entry (OctreeHit's outside test), so f starts as c itself.
+template <bool COUNT, int CL>
+TDT_DEV bool tree_lookup_pow2(const TraceParams &P, float fx, float fy, float fz, float &inv_pow_depth,
+                              float &gx, float &gy, float &gz, uint32_t &value, NodeMemo<CL> &memo, Counters &cnt) {
+  float ipd = 1.0f, ux = 0.0f, uy = 0.0f, uz = 0.0f;
+  uint32_t v = 0;
+  bool is_leaf = false;
+  const int depth = P.max_depth;
+  auto level = [&](uint32_t *mkey, uint32_t *mval) -> bool {   // returns true when the descent ends here
+    ipd = ipd * 0.5f;
+    const float fv = (float)v;
+    uint32_t ix; bool bitx;
+    if (v < (1u << 22)) {
+      const float q = (fv + fx) - fv;
+      const bool a = q > 0.5f, b = (q == 1.0f);
+      ix = 2u * v + (a ? 1u : 0u) + (b ? 1u : 0u);
+      bitx = a && !b;
+    } else {
+      const float two_cc = (float)(int32_t)((uint32_t)P.cell_count << 1);
+      const float rx = __builtin_rintf(((fv + fx) * P.inv_cell_count) * two_cc + -0.5f);
+      ix = (uint32_t)f2i(rx);
+      const float tx = __builtin_truncf(rx);
+      bitx = (tx + -(2.0f * __builtin_floorf(tx / 2.0f))) != 0.0f;   // 0 or 1 here: rx >= 2^23 - 1
+    }
+    const bool by = fy > 0.5f, bz = fz > 0.5f;
+    ux = ux + (bitx ? ipd : 0.0f); uy = uy + (by ? ipd : 0.0f); uz = uz + (bz ? ipd : 0.0f);
+    const uint32_t idx = ((ix << 2) + (by ? 2u : 0u) + (bz ? 1u : 0u)) & 0x1FFFFFFFu;
+    uint32_t code;
+    if (mkey && (*mkey & 0x1FFFFFFFu) == idx) {
+      v = *mval; code = *mkey >> 30;
+    } else {
+      const uint32_t dw = idx << 1;
+      uint32_t node_type;
+      if (dw + 1u < P.cells_dwords) {
+        uint2 n = *reinterpret_cast<const uint2 *>(P.cells + dw);
+        v = n.x; node_type = n.y;
+      } else {
+        v = (dw < P.cells_dwords) ? P.cells[dw] : 0u;
+        node_type = 0u;
+      }
+      code = (node_type == 0u) ? 0u : (node_type == 2u ? 2u : 1u);
+      if (mkey) { *mkey = idx | (code << 30); *mval = v; }
+    }
+    if (COUNT) cnt.node_loads++;
+    if (code != 1u) { is_leaf = (code == 2u); return true; }
+    const float x2 = fx + fx, y2 = fy + fy, z2 = fz + fz;
+    fx = (fx >= 0.5f) ? x2 - 1.0f : x2;
+    fy = (fy >= 0.5f) ? y2 - 1.0f : y2;
+    fz = (fz >= 0.5f) ? z2 - 1.0f : z2;
+    return false;
+  };
+  bool done = false;
+#pragma unroll
+  for (int l = 0; l < CL; l++) {
+    if (!done && l < depth) done = level(&memo.key[l], &memo.val[l]);
+  }
+  for (int l = CL; !done && l < depth; l++) done = level(nullptr, nullptr);
+  inv_pow_depth = ipd; gx = ux; gy = uy; gz = uz; value = v;
+  return is_leaf;
+}
+
 // OctreeHit rc:397-450 with t_min = 0.0003, t_max = +inf (rc:271)
-template <bool COUNT>
-TDT_DEV bool octree_hit(const TraceParams &P, const Ray &r, Carry &pc, Hit &hit, Counters &cnt) {
+template <bool COUNT, bool POW2>
+TDT_DEV bool octree_hit(const TraceParams &P, const Ray &r, Carry &pc, Hit &hit, NodeMemo<kMemoLevels> &memo, Counters &cnt) {
   const float inf = __builtin_inff();
   if (COUNT) cnt.octree_hit_calls++;
   float ix = f_rcp(r.dx), iy = f_rcp(r.dy), iz = f_rcp(r.dz);
@@ -199,13 +283,18 @@ TDT_DEV bool octree_hit(const TraceParams &P, const Ray &r, Carry &pc, Hit &hit,
     float t = t_stride + adv;
     float wx = t * r.dx + r.ox, wy = t * r.dy + r.oy, wz = t * r.dz + r.oz;
     float lx = (wx + -P.min_x) * P.inv_scale, ly = (wy + -P.min_y) * P.inv_scale, lz = (wz + -P.min_z) * P.inv_scale;
-    {
+    if (POW2) {
+      // rc:417 "fract(p) - p != vec3(0)": fract(p) - p is zero exactly for p in [0,1) (and -0)
+      const bool inside = (lx >= 0.0f) & (lx < 1.0f) & (ly >= 0.0f) & (ly < 1.0f) & (lz >= 0.0f) & (lz < 1.0f);
+      if (!inside) return false;
+    } else {
       float ex = f_fract(lx) + -lx, ey = f_fract(ly) + -ly, ez = f_fract(lz) + -lz;
       if ((__builtin_fabsf(ez) + __builtin_fabsf(ey)) != -__builtin_fabsf(ex)) return false;
     }
     float gx, gy, gz; uint32_t value;
     if (COUNT) cnt.iterations++;
-    bool leaf = tree_lookup<COUNT>(P, lx, ly, lz, inv_pow_depth, gx, gy, gz, value, cnt);
+    bool leaf = POW2 ? tree_lookup_pow2<COUNT, kMemoLevels>(P, lx, ly, lz, inv_pow_depth, gx, gy, gz, value, memo, cnt)
+                     : tree_lookup<COUNT>(P, lx, ly, lz, inv_pow_depth, gx, gy, gz, value, cnt);
     if (leaf) {
       if (i > 0) {
         float cx = gx * P.scale + P.min_x, cy = gy * P.scale + P.min_y, cz = gz * P.scale + P.min_z;
@@ -376,12 +465,12 @@ TDT_DEV Ray primary_ray(const TraceParams &P, int px, int py, int s) {
 }
 
 // RayColor rc:264-302
-template <bool COUNT>
-TDT_DEV void ray_color(const TraceParams &P, Ray r, Carry &pc, float &cr, float &cg, float &cb, Counters &cnt) {
+template <bool COUNT, bool POW2>
+TDT_DEV void ray_color(const TraceParams &P, Ray r, Carry &pc, float &cr, float &cg, float &cb, NodeMemo<kMemoLevels> &memo, Counters &cnt) {
   float ar = 1.0f, ag = 1.0f, ab = 1.0f;
   int32_t loop_count = 0;
   Hit h;
-  while (loop_count < P.max_bounce && octree_hit<COUNT>(P, r, pc, h, cnt)) {
+  while (loop_count < P.max_bounce && octree_hit<COUNT, POW2>(P, r, pc, h, memo, cnt)) {
     loop_count += 1;
     Ray nr; float tr, tg, tb;
     if (!scatter<COUNT>(P, r, h, nr, tr, tg, tb, cnt)) break;

@@ -15,7 +15,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtdtrt.so")
+# TDT_LIB: alternative build of the same library (A/B experiments); never a different implementation
+LIB_PATH = os.environ.get("TDT_LIB") or os.path.join(_HERE, "libtdtrt.so")
 
 OK, ERR_NO_DEVICE, ERR_HIP, ERR_VARIABLE_NOT_FOUND, ERR_INCOMPLETE = 0, 1, 2, 3, 4
 ERR_INVALID_ENUM, ERR_INVALID_VALUE, ERR_INVALID_OPERATION = 0x0500, 0x0501, 0x0502

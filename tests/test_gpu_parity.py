@@ -57,3 +57,20 @@ def test_dispatch_floor_division_coverage(oracle):
     got = _render_gpu(scene, cam)
     assert (got[160:, :, :] == 0).all()
     assert (got[:160, :, 3] == 1).all()
+
+
+def test_event_counts_equal_oracle(oracle):
+    """The instrumented dispatch counts exactly the events the oracle counts: they define the
+    algorithmic bytes that bench.py's roofline uses."""
+    scene = host.Scene.config(2)
+    cam = host.camera_reference_pose(256, 144, 4, 8)
+    r = rt.Renderer(scene, cam, device=0)
+    try:
+        got = r.shader.dispatch_counted(cam.image_width + 1, cam.image_height + 1, 1)
+        img = r.texture.read()
+    finally:
+        r.close()
+    ref, st = oracle.render(scene, cam, threads=8, want_stats=True)
+    assert _bits_equal(img, ref).all()
+    for k in ("pixels", "octree_hit_calls", "iterations", "node_loads", "lambertian", "metal", "dielectric", "unknown_material"):
+        assert got[k] == st[k], (k, got[k], st[k])
