@@ -158,6 +158,9 @@ int tdt_dispatch_resolve(tdt_compute *c, int width, int height, int depth, int t
  * [3] Node loads (tree levels visited), [4] Lambertian, [5] metal, [6] dielectric scatters,
  * [7] hits on unknown material types.  Synchronous.  These define the algorithmic bytes. */
 int tdt_dispatch_counted(tdt_compute *c, int width, int height, int depth, uint64_t counts[8]);
+/* lane-utilisation diagnostics of the last tdt_dispatch_counted of this context (32 totals; layout in
+ * csrc/trace_device.hpp `Counters`); development aid */
+int tdt_debug_counters(tdt_ctx *ctx, uint64_t out[32]);
 
 #ifdef __cplusplus
 }

@@ -27,15 +27,18 @@
 namespace tdt {
 
 // ---- work decomposition ------------------------------------------------------------------
-// One 256-thread block (4 wave64) owns one of the reference's 32x32 work-groups (row-major index
-// t over the covered image; t % world == rank picks this rank's groups: SURVEY §8e).  Its 1024
-// pixels are NOT bound to threads: lanes are persistent and pull the next pixel from a
-// block-local queue (one LDS counter, advanced once per wave by ballot + prefix count) whenever
-// they finish all samples of their current one, so a lane that drew cheap (sky) pixels keeps
-// working instead of idling behind the most expensive pixel of its tile.  The queue hands pixels
-// out tile-major (8x8), so the lanes of a wave stay on neighbouring pixels and share octree
-// nodes / cache lines.
-TDT_DEV void decode_pixel(const TraceParams &P, int gx, int gy, int k, uint32_t p, int &x, int &y, size_t &pix, bool &inside) {
+// Persistent 1024-thread blocks, one per CU (the block's LDS holds the top of the octree, see
+// NodeSource).  Pixels are NOT bound to threads: the covered image is a single global queue of
+// pixel slots q = k * 1024 + p — k-th 32x32 work-group owned by this rank (row-major group index
+// t = rank + k * world: SURVEY §8e), p-th pixel inside it in 8x8-tile-major order — and every lane
+// pulls its next pixel from it (one atomic per wave: ballot + prefix count) when it has finished
+// all samples of its current one.  A lane that drew cheap (sky) pixels keeps working instead of
+// idling behind the most expensive pixel of its tile, all CUs stay busy until the queue is empty,
+// and at any moment the chip works on one narrow band of the image, so neighbouring lanes share
+// octree nodes and cache lines.
+TDT_DEV void decode_pixel(const TraceParams &P, int k, uint32_t p, int &x, int &y, size_t &pix, bool &inside) {
+  const int t = P.part_rank + k * P.part_world;
+  const int gx = t % P.tiles_x, gy = t / P.tiles_x;
   const int tile = (int)(p >> 6), w = (int)(p & 63);
   const int lx = (tile & 3) * 8 + (w & 7), ly = (tile >> 2) * 8 + (w >> 3);
   x = gx * 32 + lx;
@@ -47,10 +50,8 @@ TDT_DEV void decode_pixel(const TraceParams &P, int gx, int gy, int k, uint32_t 
 // pixel addressing of the one-thread-per-pixel helper kernels (resolve)
 TDT_DEV bool pixel_of_thread(const TraceParams &P, int &x, int &y, size_t &pix) {
   const int k = blockIdx.x >> 2, sub = blockIdx.x & 3;
-  const int t = P.part_rank + k * P.part_world;
-  const int gx = t % P.tiles_x, gy = t / P.tiles_x;
   bool inside;
-  decode_pixel(P, gx, gy, k, (uint32_t)(sub * 256 + threadIdx.x), x, y, pix, inside);
+  decode_pixel(P, k, (uint32_t)(sub * 256 + threadIdx.x), x, y, pix, inside);
   return inside;
 }
 
@@ -70,16 +71,18 @@ enum : int { ST_TRAVERSE = 0, ST_HIT = 1, ST_END = 2, ST_FETCH = 3, ST_PRIMARY =
 // COUNT: instrumented build that also totals the events defining the algorithmic bytes.
 // POW2: exact-comparison treeLookup (see tree_lookup_pow2) vs the literal float form.
 template <int MODE, bool COUNT, bool POW2>
-__global__ __launch_bounds__(256, TDT_MIN_WAVES) void trace_kernel(const TraceParams P) {
-  __shared__ uint32_t s_next_pixel;
-  const int k = blockIdx.x;
-  const int t = P.part_rank + k * P.part_world;
-  const int gx = t % P.tiles_x, gy = t / P.tiles_x;
-  if (threadIdx.x == 0) s_next_pixel = 0;
+__global__ __launch_bounds__(1024) void trace_kernel(const TraceParams P) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_nodes[kLdsCells * 8];
+  for (uint32_t i = threadIdx.x * 4u; i < P.lds_nodes; i += 1024u * 4u)
+    *reinterpret_cast<uint4 *>(&s_nodes[i]) = *reinterpret_cast<const uint4 *>(&P.packed[i]);
   __syncthreads();
+  NodeSource ns;
+  ns.lds = s_nodes; ns.lds_nodes = P.lds_nodes;
+  ns.cells = __builtin_amdgcn_make_buffer_rsrc((void *)P.cells, 0, (int)((P.cells_dwords >> 1) << 3), 0x00020000);
+  const uint32_t total_slots = (uint32_t)P.owned_tiles * 1024u;
 
   const float inf = __builtin_inff();
-  Counters cnt = {0, 0, 0, 0, 0, 0, 0};
+  Counters cnt = {};
   uint32_t n_pixels = 0;
   NodeMemo<kMemoLevels> memo;
 #pragma unroll
@@ -94,7 +97,8 @@ __global__ __launch_bounds__(256, TDT_MIN_WAVES) void trace_kernel(const TracePa
   float sr = 0.f, sg = 0.f, sb = 0.f;                // color rc:237
   float t_stride = 0.f, t_octree_max = 0.f, inv_pow_depth = 0.5f;
   int it = 0;                                        // OctreeHit's i rc:410
-  bool use_leaf = false; uint32_t hit_index = 0;
+  bool use_leaf = false, leaf_rec = false; uint32_t hit_index = 0;
+  float leaf_box_x = 0.f, leaf_box_y = 0.f, leaf_box_z = 0.f;
   Carry pc;
   pc.root = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}; pc.leaf = pc.root; pc.root_t = 0.f;
   const int s_end = P.spp_begin + P.spp_count;
@@ -102,6 +106,7 @@ __global__ __launch_bounds__(256, TDT_MIN_WAVES) void trace_kernel(const TracePa
   for (;;) {
     // ------------------------------------------------------------ one traversal step rc:410-447
     if (state == ST_TRAVERSE) {
+      if (COUNT) { cnt.trav_slots += slot64(); cnt.trav_active++; }
       if (!(it < P.max_iter && t_stride < t_octree_max)) {
         state = ST_END;                               // OctreeHit returns false rc:449
       } else {
@@ -122,8 +127,8 @@ __global__ __launch_bounds__(256, TDT_MIN_WAVES) void trace_kernel(const TracePa
         } else {
           float ugx, ugy, ugz; uint32_t value;
           if (COUNT) cnt.iterations++;
-          const bool leaf = POW2 ? tree_lookup_pow2<COUNT, kMemoLevels>(P, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, memo, cnt)
-                                 : tree_lookup<COUNT>(P, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, cnt);
+          const bool leaf = POW2 ? tree_lookup_pow2<COUNT, kMemoLevels>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, memo, cnt)
+                                 : tree_lookup<COUNT>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, cnt);
           const float bx = ugx * P.scale + P.min_x, by = ugy * P.scale + P.min_y, bz = ugz * P.scale + P.min_z;
           const float cs0 = P.scale * inv_pow_depth;
           // leaf: the exact cell (rc:427-428); empty: padded by -1e-5 / +2e-5 (rc:441-442)
@@ -133,8 +138,11 @@ __global__ __launch_bounds__(256, TDT_MIN_WAVES) void trace_kernel(const TracePa
           cube_slabs(r, ix, iy, iz, cx, cy, cz, cs, t_stride, t_octree_max, t_enter, t_exit);
           const bool cube_ok = !(t_exit < t_enter);
           if (leaf) {
-            if (it > 0 && cube_ok) cube_hit_record(r, t_enter, cx, cy, cz, cs, pc.leaf);
-            use_leaf = it > 0; hit_index = value;
+            // CubeHit's record (rc:336-354) is deferred to the event code, where the lanes that hit
+            // are batched: only a few lanes per step reach a leaf.  The traversal registers are
+            // dead from here on, so they carry the cube.
+            leaf_box_x = cx; leaf_box_y = cy; leaf_box_z = cz; inv_pow_depth = cs; t_stride = t_enter;
+            use_leaf = it > 0; leaf_rec = it > 0 && cube_ok; hit_index = value;
             state = ST_HIT;
           } else {
             t_stride = cube_ok ? t_exit : t_octree_max;
@@ -151,7 +159,10 @@ __global__ __launch_bounds__(256, TDT_MIN_WAVES) void trace_kernel(const TracePa
     // run the (long, material-divergent) event code only when enough lanes wait for it
     if (__popcll(m_event) < TDT_EVENT_THRESHOLD && m_trav != 0ull) continue;
 
+    if (COUNT) { cnt.event_slots += slot64(); cnt.event_active += (state != ST_TRAVERSE && state != ST_DONE); }
     if (state == ST_HIT) {                            // RayColor loop body rc:272-295
+      if (COUNT) { cnt.scatter_slots += slot64(); cnt.scatter_active++; }
+      if (leaf_rec) { cube_hit_record(r, t_stride, leaf_box_x, leaf_box_y, leaf_box_z, inv_pow_depth, pc.leaf); if (COUNT) cnt.leaf_records++; }
       loop_count += 1;
       const HitTmp &src = use_leaf ? pc.leaf : pc.root;
       Hit h;
@@ -205,14 +216,14 @@ __global__ __launch_bounds__(256, TDT_MIN_WAVES) void trace_kernel(const TracePa
       const unsigned long long m = __ballot(want);
       if (m != 0ull) {
         uint32_t base = 0;
-        if ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&s_next_pixel, (uint32_t)__popcll(m));
+        if ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(P.queue, (uint32_t)__popcll(m));
         base = (uint32_t)__shfl((int)base, __builtin_ctzll(m), 64);
         if (want) {
-          const uint32_t p = base + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
-          if (p >= 1024u) state = ST_DONE;
+          const uint32_t q = base + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+          if (q >= total_slots) state = ST_DONE;
           else {
             bool inside;
-            decode_pixel(P, gx, gy, k, p, x, y, pix, inside);
+            decode_pixel(P, (int)(q >> 10), q & 1023u, x, y, pix, inside);
             if (inside) {                             // outside the covered image: ask again next time
               n_pixels++;
               sr = 0.f; sg = 0.f; sb = 0.f; s = P.spp_begin;
@@ -270,9 +281,11 @@ __global__ __launch_bounds__(256, TDT_MIN_WAVES) void trace_kernel(const TracePa
   }
 
   if (COUNT) {
-    uint32_t v[8] = {n_pixels, cnt.octree_hit_calls, cnt.iterations, cnt.node_loads,
-                     cnt.lambertian, cnt.metal, cnt.dielectric, cnt.unknown};
-    for (int i = 0; i < 8; i++) {
+    uint32_t v[18] = {n_pixels, cnt.octree_hit_calls, cnt.iterations, cnt.node_loads,
+                      cnt.lambertian, cnt.metal, cnt.dielectric, cnt.unknown,
+                      cnt.trav_slots, cnt.trav_active, cnt.level_slots, cnt.level_active, cnt.event_slots, cnt.event_active,
+                      cnt.scatter_slots, cnt.scatter_active, cnt.memo_miss, cnt.leaf_records};
+    for (int i = 0; i < 18; i++) {
       uint32_t tot = wave_sum(v[i]);
       if ((threadIdx.x & 63) == 0 && tot) atomicAdd(&P.counters[i], (unsigned long long)tot);
     }
@@ -291,6 +304,17 @@ __global__ __launch_bounds__(256) void resolve_kernel(const TraceParams P) {
   o.z = f_min(f_max(__builtin_sqrtf(a.z / n), 0.f), 1.f);
   o.w = 1.0f;
   *dst = o;
+}
+
+// Re-encode the first n nodes of the cells payload as one dword each for the LDS table (NodeSource).
+__global__ __launch_bounds__(256) void pack_cells_kernel(const uint32_t *__restrict__ cells, uint32_t cells_dwords,
+                                                        uint32_t *__restrict__ packed, uint32_t n_nodes) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n_nodes) return;
+  uint32_t value = 0, type = 0;
+  if (2u * i + 1u < cells_dwords) { value = cells[2u * i]; type = cells[2u * i + 1u]; }   // 8-byte granules, as fetch_node
+  const uint32_t code = (type == 0u) ? 0u : (type == 2u ? 2u : 1u);
+  packed[i] = (value < (1u << 30)) ? ((value << 2) | code) : kPackedEscape;
 }
 
 // De-interleave gathered per-rank tile buffers ([rank][k][32][32] RGBA) into a W x H image.
@@ -318,6 +342,7 @@ struct tdt_buffer {
   tdt_ctx *ctx;
   void *dev;
   size_t bytes;
+  unsigned long long version;   // bumped by every write: invalidates derived data (LDS table image)
   unsigned char shadow[64];   // first bytes, host side: the octree uniform blocks are read from here
 };
 
@@ -337,6 +362,11 @@ struct tdt_ctx {
   tdt_buffer *atomic0;
   tdt_image *image0;
   unsigned long long *counters;
+  unsigned int *queue;          // pixel-queue head
+  uint32_t *packed;             // LDS-table image of the bound cells buffer
+  const tdt_buffer *packed_of;  // which buffer/version `packed` was built from
+  unsigned long long packed_version;
+  int num_cus;
   bool force_generic;   // TDT_FORCE_GENERIC=1: always run the literal-arithmetic kernel (A/B testing)
   std::vector<tdt_buffer *> buffers;
   std::vector<tdt_image *> images;
@@ -445,13 +475,35 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
   P.spp_begin = spp_begin; P.spp_count = spp_count; P.mode = mode; P.total_spp = total_spp;
 
   TDT_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->ssbo[TDT_SLOT_CELLS]->bytes > 0xFFFFFFF8ull)
+    return fail(ctx, TDT_ERR_INVALID_VALUE, "cells buffer larger than 4 GiB is not addressable by the shader's 32-bit offsets");
   if (counts_out) {
-    if (!ctx->counters) TDT_HIP(ctx, hipMalloc((void **)&ctx->counters, 8 * sizeof(unsigned long long)));
-    TDT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    if (!ctx->counters) TDT_HIP(ctx, hipMalloc((void **)&ctx->counters, 32 * sizeof(unsigned long long)));
+    TDT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, 32 * sizeof(unsigned long long), ctx->stream));
     P.counters = ctx->counters;
   }
+  if (t.owned > 0 && mode != 2) {
+    // LDS-table image of the bound cells buffer (rebuilt only when the buffer or its contents changed)
+    const tdt_buffer *cb = ctx->ssbo[TDT_SLOT_CELLS];
+    if (!ctx->packed) TDT_HIP(ctx, hipMalloc((void **)&ctx->packed, (size_t)tdt::kLdsCells * 8 * sizeof(uint32_t)));
+    if (!ctx->queue) TDT_HIP(ctx, hipMalloc((void **)&ctx->queue, sizeof(unsigned int)));
+    const uint32_t buf_nodes = P.cells_dwords >> 1;
+    P.lds_nodes = buf_nodes < tdt::kLdsCells * 8u ? (buf_nodes & ~3u) : tdt::kLdsCells * 8u;
+    if (ctx->packed_of != cb || ctx->packed_version != cb->version) {
+      if (P.lds_nodes)
+        hipLaunchKernelGGL(tdt::pack_cells_kernel, dim3((P.lds_nodes + 255) / 256), dim3(256), 0, ctx->stream,
+                           P.cells, P.cells_dwords, ctx->packed, P.lds_nodes);
+      TDT_HIP(ctx, hipGetLastError());
+      ctx->packed_of = cb; ctx->packed_version = cb->version;
+    }
+    P.packed = ctx->packed; P.queue = ctx->queue;
+    TDT_HIP(ctx, hipMemsetAsync(ctx->queue, 0, sizeof(unsigned int), ctx->stream));
+  }
   if (t.owned > 0) {
-    dim3 grid((unsigned)t.owned, 1, 1), grid4((unsigned)t.owned * 4u, 1, 1), block(256, 1, 1);
+    // trace: one persistent block per CU (fewer when there is less work than lanes); resolve: a thread per pixel
+    unsigned nblk = (unsigned)(((long)t.owned * 1024 + 1023) / 1024);
+    if (nblk > (unsigned)ctx->num_cus) nblk = (unsigned)ctx->num_cus;
+    dim3 grid(nblk, 1, 1), block(1024, 1, 1), grid4((unsigned)t.owned * 4u, 1, 1), block4(256, 1, 1);
     // the exact-comparison form of treeLookup needs cell_count = 2^k <= 2^22 and inv_cell_count = 2^-k
     // bit-for-bit (true for every scene Octree::init_global_buffers builds from such a count,
     // octree.rs:49); anything else (e.g. the demo scene's 100000) takes the literal float form
@@ -463,7 +515,7 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     if (mode == 0 && !counts_out) TDT_LAUNCH(0, false);
     else if (mode == 0) TDT_LAUNCH(0, true);
     else if (mode == 1) TDT_LAUNCH(1, false);
-    else hipLaunchKernelGGL(tdt::resolve_kernel, grid4, block, 0, ctx->stream, P);
+    else hipLaunchKernelGGL(tdt::resolve_kernel, grid4, block4, 0, ctx->stream, P);
 #undef TDT_LAUNCH
     TDT_HIP(ctx, hipGetLastError());
   }
@@ -492,7 +544,8 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
   if (!ctx) return fail(nullptr, TDT_ERR_HIP, "out of host memory");
   ctx->device = device_id;
   for (auto &s : ctx->ssbo) s = nullptr;
-  ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr;
+  ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr; ctx->queue = nullptr; ctx->packed = nullptr; ctx->packed_of = nullptr; ctx->packed_version = 0;
+  { hipDeviceProp_t prop; ctx->num_cus = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
   { const char *fg = getenv("TDT_FORCE_GENERIC"); ctx->force_generic = fg && fg[0] == '1'; }
   if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
   else {
@@ -512,6 +565,8 @@ void tdt_ctx_destroy(tdt_ctx *ctx) {
   for (tdt_buffer *b : ctx->buffers) { (void)hipFree(b->dev); delete b; }
   for (tdt_image *i : ctx->images) { if (i->owned) (void)hipFree(i->dev); delete i; }
   if (ctx->counters) (void)hipFree(ctx->counters);
+  if (ctx->queue) (void)hipFree(ctx->queue);
+  if (ctx->packed) (void)hipFree(ctx->packed);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -612,6 +667,8 @@ int tdt_buffer_create(tdt_ctx *ctx, const void *data, size_t bytes, tdt_buffer *
   tdt_buffer *b = new (std::nothrow) tdt_buffer();
   if (!b) return fail(ctx, TDT_ERR_HIP, "out of host memory");
   b->ctx = ctx; b->bytes = bytes; b->dev = nullptr;
+  static unsigned long long next_version = 1;
+  b->version = next_version++;
   std::memset(b->shadow, 0, sizeof b->shadow);
   TDT_HIP(ctx, hipSetDevice(ctx->device));
   // 16 bytes of zero slack so that the widest load at the last valid dword stays inside the allocation
@@ -664,6 +721,7 @@ int tdt_buffer_sub_data(tdt_buffer *b, size_t offset, size_t bytes, const void *
   TDT_HIP(ctx, hipSetDevice(ctx->device));
   TDT_HIP(ctx, hipMemcpyAsync((char *)b->dev + offset, data, bytes, hipMemcpyHostToDevice, ctx->stream));
   TDT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  b->version += 0x100000000ull;
   if (offset < sizeof b->shadow) {
     size_t n = sizeof b->shadow - offset; if (n > bytes) n = bytes;
     std::memcpy(b->shadow + offset, data, n);
@@ -778,6 +836,14 @@ int tdt_dispatch_counted(tdt_compute *c, int width, int height, int depth, uint6
   static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "");
   return launch(c, width, height, depth, 0, 0, c->samples_per_pixel, nullptr, c->samples_per_pixel,
                 reinterpret_cast<unsigned long long *>(counts));
+}
+
+/* lane-utilisation diagnostics of the last tdt_dispatch_counted on this context (see Counters) */
+int tdt_debug_counters(tdt_ctx *ctx, uint64_t out[32]) {
+  if (!ctx || !out || !ctx->counters) return TDT_ERR_INVALID_VALUE;
+  TDT_HIP(ctx, hipSetDevice(ctx->device));
+  TDT_HIP(ctx, hipMemcpy(out, ctx->counters, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return TDT_OK;
 }
 
 int tdt_assemble_tiles(tdt_compute *c, const void *gathered, int world, int tiles_per_rank, tdt_image *dst,

@@ -94,8 +94,48 @@ TDT_DEV uint32_t ld_dw(const uint32_t *buf, uint32_t dwords, uint32_t byte_off) 
   return (i < dwords) ? buf[i] : 0u;
 }
 
+// ---- octree node fetch ----------------------------------------------------------------------
+// The first kLdsCells cells of the breadth-first cell array (= the top levels of the tree, or the
+// whole tree for a 64^3 scene) are staged in LDS by every block, one dword per node
+// (value << 2 | code; code 0 EMPTY, 1 PARENT / any other type, 2 LEAF; 0xFFFFFFFF = value does not
+// fit, read the original).  Everything else comes from the linearised octree in HBM / L2 through
+// a raw buffer descriptor whose range check IS the reference's robust-access rule (reads past the
+// end return 0), so there is no bounds branch.
+constexpr uint32_t kLdsCells = 4608;                 // 4608 cells * 8 nodes * 4 B = 147,456 B of the 160 KiB LDS
+constexpr uint32_t kPackedEscape = 0xFFFFFFFFu;
+
+struct NodeSource {
+  const uint32_t *lds;                                // LDS table
+  uint32_t lds_nodes;                                 // valid entries
+  __amdgpu_buffer_rsrc_t cells;                       // raw buffer over the cells payload (8-byte granules)
+};
+
+// returns the node's value; code = 0 EMPTY, 2 LEAF, 1 otherwise (rc:384-386 only distinguishes these)
+TDT_DEV uint32_t fetch_node(const NodeSource &ns, uint32_t idx, uint32_t &code) {
+  idx &= 0x1FFFFFFFu;                                 // byte offset idx << 3 wraps at 32 bits (rc:184 on a 32-bit offset)
+  if (idx < ns.lds_nodes) {
+    const uint32_t n = ns.lds[idx];
+    if (n != kPackedEscape) { code = n & 3u; return n >> 2; }
+  }
+  const auto n2 = __builtin_amdgcn_raw_buffer_load_b64(ns.cells, (int)(idx << 3), 0, 0);
+  const uint32_t node_type = (uint32_t)n2[1];
+  code = (node_type == 0u) ? 0u : (node_type == 2u ? 2u : 1u);
+  return (uint32_t)n2[0];
+}
+
 // event counts of an instrumented launch (defines the algorithmic bytes)
-struct Counters { uint32_t octree_hit_calls, iterations, node_loads, lambertian, metal, dielectric, unknown; };
+struct Counters {
+  uint32_t octree_hit_calls, iterations, node_loads, lambertian, metal, dielectric, unknown;
+  // lane-utilisation diagnostics (instrumented builds only): *_slots counts 64 per wave-level
+  // execution of a code region, *_active the lanes that were live in it
+  uint32_t trav_slots, trav_active, level_slots, level_active, event_slots, event_active,
+           scatter_slots, scatter_active, memo_miss, leaf_records;
+};
+// 64 for the first active lane of the wave, 0 for the others
+TDT_DEV uint32_t slot64() {
+  const unsigned long long m = __ballot(1);
+  return ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(m)) ? 64u : 0u;
+}
 
 struct Ray { float ox, oy, oz, dx, dy, dz; };
 // what one CubeHit call site last produced (rc:336-354); the root and leaf call sites keep
@@ -137,7 +177,7 @@ TDT_DEV void cube_slabs(const Ray &r, float ix, float iy, float iz, float cx, fl
 
 // treeLookup rc:359-394: one dependent 8-byte Node load per level
 template <bool COUNT>
-TDT_DEV bool tree_lookup(const TraceParams &P, float cx, float cy, float cz, float &inv_pow_depth,
+TDT_DEV bool tree_lookup(const TraceParams &P, const NodeSource &ns, float cx, float cy, float cz, float &inv_pow_depth,
                          float &gx, float &gy, float &gz, uint32_t &value, Counters &cnt) {
   float ipd = 1.0f, ux = 0.0f, uy = 0.0f, uz = 0.0f;
   uint32_t node_value = 0;
@@ -158,15 +198,8 @@ TDT_DEV bool tree_lookup(const TraceParams &P, float cx, float cy, float cz, flo
     ux = ux + bx * ipd; uy = uy + by * ipd; uz = uz + bz * ipd;
     uint32_t idx = (((uint32_t)ix << 1) + (uint32_t)iy);
     idx = (idx << 1) + (uint32_t)iz;
-    uint32_t dw = (idx << 3) >> 2;
     uint32_t node_type;
-    if (dw + 1u < P.cells_dwords) {
-      uint2 n = *reinterpret_cast<const uint2 *>(P.cells + dw);
-      node_value = n.x; node_type = n.y;
-    } else {
-      node_value = (dw < P.cells_dwords) ? P.cells[dw] : 0u;
-      node_type = 0u;
-    }
+    node_value = fetch_node(ns, idx, node_type);
     if (COUNT) cnt.node_loads++;
     if (node_type == 0u || node_type == 2u) { is_leaf = (node_type == 2u); break; }
     cx = cx * 2.0f; cy = cy * 2.0f; cz = cz * 2.0f;
@@ -195,9 +228,12 @@ constexpr int kMemoLevels = 9;
 // Coordinates: the reference recomputes fract(c * 2^l) per level; fract(2 f) is the same number
 // (all exact), and c in [0,1) on entry (OctreeHit's outside test), so f starts as c itself.
 template <bool COUNT, int CL>
-TDT_DEV bool tree_lookup_pow2(const TraceParams &P, float fx, float fy, float fz, float &inv_pow_depth,
+TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float fx, float fy, float fz, float &inv_pow_depth,
                               float &gx, float &gy, float &gz, uint32_t &value, NodeMemo<CL> &memo, Counters &cnt) {
-  float ipd = 1.0f, ux = 0.0f, uy = 0.0f, uz = 0.0f;
+  // grid_uv += bit * 2^-level (rc:378-379) is an exact sum of distinct powers of two: keep the
+  // bits as integers and convert once at the end (same value, 3 instead of 6 ops per level)
+  float ipd = 1.0f;
+  uint32_t qx = 0, qy = 0, qz = 0;
   uint32_t v = 0;
   bool is_leaf = false;
   const int depth = P.max_depth;
@@ -218,22 +254,15 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, float fx, float fy, float fz
       bitx = (tx + -(2.0f * __builtin_floorf(tx / 2.0f))) != 0.0f;   // 0 or 1 here: rx >= 2^23 - 1
     }
     const bool by = fy > 0.5f, bz = fz > 0.5f;
-    ux = ux + (bitx ? ipd : 0.0f); uy = uy + (by ? ipd : 0.0f); uz = uz + (bz ? ipd : 0.0f);
+    qx = (qx << 1) | (bitx ? 1u : 0u); qy = (qy << 1) | (by ? 1u : 0u); qz = (qz << 1) | (bz ? 1u : 0u);
     const uint32_t idx = ((ix << 2) + (by ? 2u : 0u) + (bz ? 1u : 0u)) & 0x1FFFFFFFu;
     uint32_t code;
+    if (COUNT) { cnt.level_slots += slot64(); cnt.level_active++; }
     if (mkey && (*mkey & 0x1FFFFFFFu) == idx) {
       v = *mval; code = *mkey >> 30;
     } else {
-      const uint32_t dw = idx << 1;
-      uint32_t node_type;
-      if (dw + 1u < P.cells_dwords) {
-        uint2 n = *reinterpret_cast<const uint2 *>(P.cells + dw);
-        v = n.x; node_type = n.y;
-      } else {
-        v = (dw < P.cells_dwords) ? P.cells[dw] : 0u;
-        node_type = 0u;
-      }
-      code = (node_type == 0u) ? 0u : (node_type == 2u ? 2u : 1u);
+      if (COUNT) cnt.memo_miss++;
+      v = fetch_node(ns, idx, code);
       if (mkey) { *mkey = idx | (code << 30); *mval = v; }
     }
     if (COUNT) cnt.node_loads++;
@@ -250,71 +279,8 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, float fx, float fy, float fz
     if (!done && l < depth) done = level(&memo.key[l], &memo.val[l]);
   }
   for (int l = CL; !done && l < depth; l++) done = level(nullptr, nullptr);
-  inv_pow_depth = ipd; gx = ux; gy = uy; gz = uz; value = v;
+  inv_pow_depth = ipd; gx = (float)qx * ipd; gy = (float)qy * ipd; gz = (float)qz * ipd; value = v;
   return is_leaf;
-}
-
-// OctreeHit rc:397-450 with t_min = 0.0003, t_max = +inf (rc:271)
-template <bool COUNT, bool POW2>
-TDT_DEV bool octree_hit(const TraceParams &P, const Ray &r, Carry &pc, Hit &hit, NodeMemo<kMemoLevels> &memo, Counters &cnt) {
-  const float inf = __builtin_inff();
-  if (COUNT) cnt.octree_hit_calls++;
-  float ix = f_rcp(r.dx), iy = f_rcp(r.dy), iz = f_rcp(r.dz);
-  float t_enter, t_exit;
-  {
-    float lx = (P.min_x + -r.ox) * ix, ly = (P.min_y + -r.oy) * iy, lz = (P.min_z + -r.oz) * iz;
-    float ux = ((P.min_x + P.scale) + -r.ox) * ix, uy = ((P.min_y + P.scale) + -r.oy) * iy,
-          uz = ((P.min_z + P.scale) + -r.oz) * iz;
-    float mnx = f_min(lx, ux), mny = f_min(ly, uy), mnz = f_min(lz, uz);
-    float mxx = f_max(lx, ux), mxy = f_max(ly, uy), mxz = f_max(lz, uz);
-    t_enter = f_max(f_max(f_max(mnx, 0.0003f), mny), mnz);
-    t_exit = f_min(f_min(f_min(mxx, inf), mxy), mxz);
-  }
-  float t_octree_max = inf;
-  if (t_exit >= t_enter) {
-    cube_hit_record(r, t_enter, P.min_x, P.min_y, P.min_z, P.scale, pc.root);
-    pc.root_t = t_enter;
-    t_octree_max = t_exit;
-  }
-  float t_stride = pc.root_t;
-  float inv_pow_depth = 0.5f;
-  for (int32_t i = 0; i < P.max_iter && t_stride < t_octree_max; i++) {
-    float adv = f_max(0.0001f * (inv_pow_depth + 0.1f), 0.000001f);
-    float t = t_stride + adv;
-    float wx = t * r.dx + r.ox, wy = t * r.dy + r.oy, wz = t * r.dz + r.oz;
-    float lx = (wx + -P.min_x) * P.inv_scale, ly = (wy + -P.min_y) * P.inv_scale, lz = (wz + -P.min_z) * P.inv_scale;
-    if (POW2) {
-      // rc:417 "fract(p) - p != vec3(0)": fract(p) - p is zero exactly for p in [0,1) (and -0)
-      const bool inside = (lx >= 0.0f) & (lx < 1.0f) & (ly >= 0.0f) & (ly < 1.0f) & (lz >= 0.0f) & (lz < 1.0f);
-      if (!inside) return false;
-    } else {
-      float ex = f_fract(lx) + -lx, ey = f_fract(ly) + -ly, ez = f_fract(lz) + -lz;
-      if ((__builtin_fabsf(ez) + __builtin_fabsf(ey)) != -__builtin_fabsf(ex)) return false;
-    }
-    float gx, gy, gz; uint32_t value;
-    if (COUNT) cnt.iterations++;
-    bool leaf = POW2 ? tree_lookup_pow2<COUNT, kMemoLevels>(P, lx, ly, lz, inv_pow_depth, gx, gy, gz, value, memo, cnt)
-                     : tree_lookup<COUNT>(P, lx, ly, lz, inv_pow_depth, gx, gy, gz, value, cnt);
-    if (leaf) {
-      if (i > 0) {
-        float cx = gx * P.scale + P.min_x, cy = gy * P.scale + P.min_y, cz = gz * P.scale + P.min_z;
-        float cs = P.scale * inv_pow_depth;
-        cube_slabs(r, ix, iy, iz, cx, cy, cz, cs, t_stride, t_octree_max, t_enter, t_exit);
-        if (!(t_exit < t_enter)) cube_hit_record(r, t_enter, cx, cy, cz, cs, pc.leaf);
-      }
-      const HitTmp &src = (i > 0) ? pc.leaf : pc.root;
-      hit.px = src.px; hit.py = src.py; hit.pz = src.pz;
-      hit.nx = src.nx; hit.ny = src.ny; hit.nz = src.nz;
-      hit.ff = src.ff; hit.index = value;
-      return true;
-    }
-    float cx = (gx * P.scale + P.min_x) + -0.00001f, cy = (gy * P.scale + P.min_y) + -0.00001f,
-          cz = (gz * P.scale + P.min_z) + -0.00001f;
-    float cs = P.scale * inv_pow_depth + 0.00002f;
-    cube_slabs(r, ix, iy, iz, cx, cy, cz, cs, t_stride, t_octree_max, t_enter, t_exit);
-    t_stride = (!(t_exit < t_enter)) ? t_exit : t_octree_max;
-  }
-  return false;
 }
 
 TDT_DEV float rand2(float cx, float cy) {   // Rand(vec2) rc:53
@@ -462,25 +428,6 @@ TDT_DEV Ray primary_ray(const TraceParams &P, int px, int py, int s) {
   float rs = f_rsq((rz * rz + ry * ry) + rx * rx);
   Ray r = { P.org[0], P.org[1], P.org[2], rx * rs, ry * rs, rz * rs };
   return r;
-}
-
-// RayColor rc:264-302
-template <bool COUNT, bool POW2>
-TDT_DEV void ray_color(const TraceParams &P, Ray r, Carry &pc, float &cr, float &cg, float &cb, NodeMemo<kMemoLevels> &memo, Counters &cnt) {
-  float ar = 1.0f, ag = 1.0f, ab = 1.0f;
-  int32_t loop_count = 0;
-  Hit h;
-  while (loop_count < P.max_bounce && octree_hit<COUNT, POW2>(P, r, pc, h, memo, cnt)) {
-    loop_count += 1;
-    Ray nr; float tr, tg, tb;
-    if (!scatter<COUNT>(P, r, h, nr, tr, tg, tb, cnt)) break;
-    ar = ar * tr; ag = ag * tg; ab = ab * tb;
-    r = nr;
-  }
-  if (loop_count > 0) { cr = ar; cg = ag; cb = ab; return; }
-  float yp = r.dy + 1.0f;
-  float w = 1.0f + -(0.5f * yp);
-  cr = w + 0.25f * yp; cg = w + 0.35f * yp; cb = 1.0f;
 }
 
 }  // namespace tdt

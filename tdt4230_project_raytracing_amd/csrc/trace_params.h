@@ -20,7 +20,10 @@ struct TraceParams {
   // output image (RGBA32F, row 0 = bottom) and optional per-pixel carry (16 floats / pixel)
   float *image;
   float *carry;
-  unsigned long long *counters; // instrumented launches only: 8 event totals (see Counters)
+  unsigned long long *counters; // instrumented launches only: event totals (see Counters)
+  unsigned int *queue;          // global pixel queue head (zeroed before every launch)
+  const uint32_t *packed;       // cells [0, lds_cells) re-encoded as one dword per node: value << 2 | code
+  uint32_t lds_nodes;           // number of nodes (8 per cell) staged in LDS by every block
   int32_t compact;             // 1: image is this rank's tile buffer [owned tile k][32][32] RGBA
   int32_t cover_w, cover_h;    // pixels a dispatch covers: min(32*groups, image size)
   int32_t tiles_x;             // 32x32 work-groups per row = ceil(cover_w / 32)

@@ -59,6 +59,7 @@ SYMBOLS = [
     ("tdt_owned_tiles", _I, [_P, _I, _I, _I, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     ("tdt_assemble_tiles", _I, [_P, _P, _I, _I, _P, _I, _I, _I]),
     ("tdt_dispatch_counted", _I, [_P, _I, _I, _I, ctypes.POINTER(ctypes.c_uint64)]),
+    ("tdt_debug_counters", _I, [_P, ctypes.POINTER(ctypes.c_uint64)]),
 ]
 
 _lib = None
@@ -238,6 +239,14 @@ class ComputeShader:
 
     COUNT_FIELDS = ("pixels", "octree_hit_calls", "iterations", "node_loads", "lambertian", "metal", "dielectric",
                     "unknown_material")
+
+    DEBUG_FIELDS = ("trav_slots", "trav_active", "level_slots", "level_active", "event_slots", "event_active",
+                    "scatter_slots", "scatter_active", "memo_miss", "leaf_records")
+
+    def debug_counters(self):
+        c = (ctypes.c_uint64 * 32)()
+        self.ctx.check(lib().tdt_debug_counters(self.ctx.h, c))
+        return dict(zip(self.DEBUG_FIELDS, [int(v) for v in c[8:18]]))
 
     def dispatch_counted(self, width, height, depth=1):
         """Instrumented dispatch: event totals that define the algorithmic bytes."""
