@@ -262,10 +262,10 @@ __global__ __launch_bounds__(1024) void trace_kernel(const TraceParams P) {
         const float lx = (P.min_x + -r.ox) * ix, ly = (P.min_y + -r.oy) * iy, lz = (P.min_z + -r.oz) * iz;
         const float ux = ((P.min_x + P.scale) + -r.ox) * ix, uy = ((P.min_y + P.scale) + -r.oy) * iy,
                     uz = ((P.min_z + P.scale) + -r.oz) * iz;
-        const float mnx = f_min(lx, ux), mny = f_min(ly, uy), mnz = f_min(lz, uz);
-        const float mxx = f_max(lx, ux), mxy = f_max(ly, uy), mxz = f_max(lz, uz);
-        const float t_enter = f_max(f_max(f_max(mnx, 0.0003f), mny), mnz);
-        const float t_exit = f_min(f_min(f_min(mxx, inf), mxy), mxz);
+        const float mnx = hw_min(lx, ux), mny = hw_min(ly, uy), mnz = hw_min(lz, uz);
+        const float mxx = hw_max(lx, ux), mxy = hw_max(ly, uy), mxz = hw_max(lz, uz);
+        const float t_enter = hw_max(hw_max(hw_max(mnx, 0.0003f), mny), mnz);
+        const float t_exit = hw_min(hw_min(hw_min(mxx, inf), mxy), mxz);
         t_octree_max = inf;
         if (t_exit >= t_enter) {
           cube_hit_record(r, t_enter, P.min_x, P.min_y, P.min_z, P.scale, pc.root);
@@ -509,7 +509,7 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     // octree.rs:49); anything else (e.g. the demo scene's 100000) takes the literal float form
     const uint32_t cc = (uint32_t)P.cell_count;
     const bool pow2 = !ctx->force_generic && P.cell_count > 0 && (cc & (cc - 1)) == 0 && cc <= (1u << 22) &&
-                      P.inv_cell_count == 1.0f / (float)cc && P.max_depth <= 32;
+                      P.inv_cell_count == 1.0f / (float)cc && P.max_depth >= 0 && P.max_depth <= 30;
 #define TDT_LAUNCH(M, C) do { if (pow2) hipLaunchKernelGGL((tdt::trace_kernel<M, C, true>), grid, block, 0, ctx->stream, P); \
                               else hipLaunchKernelGGL((tdt::trace_kernel<M, C, false>), grid, block, 0, ctx->stream, P); } while (0)
     if (mode == 0 && !counts_out) TDT_LAUNCH(0, false);

@@ -208,79 +208,104 @@ TDT_DEV bool tree_lookup(const TraceParams &P, const NodeSource &ns, float cx, f
   return is_leaf;
 }
 
-// Per-lane memo of the last node fetched at each of the first CL levels.  The scene is
-// read-only, so "node idx at level l" fetched for the previous traversal step is still the
-// node: consecutive steps of a ray (and consecutive rays of a pixel) share most of their root
-// path, which turns the reference's restart-from-root into ~1 dependent load per step without
-// changing a single decision.  key = node index (29 bits) | type code << 30.
+// Per-lane memo of the last node fetched from HBM/L2 at each of CL levels (levels kMemoFirst+1 ..
+// kMemoFirst+CL; shallower levels always sit in the LDS table).  The scene is read-only, so
+// "node idx at level l" fetched for the previous traversal step is still the node: consecutive
+// steps of a ray (and consecutive rays of a pixel) share most of their root path, which turns the
+// reference's restart-from-root into ~1 dependent load per step without changing a decision.
+// key = node index (29 bits) | code << 30.
 template <int CL>
 struct NodeMemo { uint32_t key[CL]; uint32_t val[CL]; };
 constexpr int kMemoLevels = 9;
+constexpr int kMemoFirst = 3;       // levels 1..3 = cells 0..72 at most: always inside the LDS table
 
-// treeLookup rc:359-394 specialised for cell_count = 2^k <= 2^22 with inv_cell_count = 2^-k
-// (checked on the host), where the float index arithmetic collapses to exact comparisons:
-//   y,z: round_even(f*2 - 0.5) = (f > 0.5)                       [f in [0,1)]
+// treeLookup rc:359-394 specialised for cell_count = 2^k <= 2^22 with inv_cell_count = 2^-k and
+// max_depth <= 30 (checked on the host), where the float index arithmetic collapses to exact
+// integer / comparison forms:
+//   y,z: round_even(f*2 - 0.5) = (f > 0.5) for f = fract(c * 2^(l-1)) in [0,1).  Over all levels
+//        these are the binary digits of floor(c * 2^D), except that an exact tie (f == 0.5: c * 2^D
+//        an integer whose lowest set bit is this level's) picks the LOWER child and all-zero
+//        digits below it: clear the lowest set bit when c * 2^D is an integer.  One integer per
+//        axis, computed once per lookup; a level is one bit-field extract.
 //   x  : ((v + fx) * 2^-k) * 2^(k+1) - 0.5 = 2*s - 0.5 exactly, s = fl(float(v) + fx); with
 //        q = s - float(v) (exact) round_even gives 2v + (q > 0.5) + (q == 1): the second term is
 //        the reference's own rounding artefact (fx rounded up to 1.0 at large v lands in the
 //        NEXT cell), kept.  Needs v < 2^22 so that 2s - 0.5 is exact; larger v takes the
-//        literal formula.
-// Coordinates: the reference recomputes fract(c * 2^l) per level; fract(2 f) is the same number
-// (all exact), and c in [0,1) on entry (OctreeHit's outside test), so f starts as c itself.
+//        literal formula.  fx needs the float recurrence fract(2 f) (exact).
+// Coordinates: c in [0,1) on entry (OctreeHit's outside test), so f starts as c itself.
 template <bool COUNT, int CL>
 TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float fx, float fy, float fz, float &inv_pow_depth,
                               float &gx, float &gy, float &gz, uint32_t &value, NodeMemo<CL> &memo, Counters &cnt) {
-  // grid_uv += bit * 2^-level (rc:378-379) is an exact sum of distinct powers of two: keep the
-  // bits as integers and convert once at the end (same value, 3 instead of 6 ops per level)
-  float ipd = 1.0f;
-  uint32_t qx = 0, qy = 0, qz = 0;
-  uint32_t v = 0;
-  bool is_leaf = false;
   const int depth = P.max_depth;
-  auto level = [&](uint32_t *mkey, uint32_t *mval) -> bool {   // returns true when the descent ends here
-    ipd = ipd * 0.5f;
+  const float scale_d = __uint_as_float((uint32_t)(127 + depth) << 23);     // 2^depth
+  const float Yf = fy * scale_d, Zf = fz * scale_d;                        // exact
+  const float Yfl = __builtin_floorf(Yf), Zfl = __builtin_floorf(Zf);
+  uint32_t Yi = (uint32_t)Yfl, Zi = (uint32_t)Zfl;
+  Yi = (Yf == Yfl) ? (Yi & (Yi - 1u)) : Yi;
+  Zi = (Zf == Zfl) ? (Zi & (Zi - 1u)) : Zi;
+  uint32_t qx = 0, v = 0, code = 1u;
+  int m = 0;                                          // levels visited
+  auto level = [&](int l, uint32_t *mkey, uint32_t *mval) {    // l = 1-based level
+    const int sh = depth - l;
     const float fv = (float)v;
-    uint32_t ix; bool bitx;
-    if (v < (1u << 22)) {
+    uint32_t ix; uint32_t bitx;
+    if (__builtin_expect(__ballot(v >= (1u << 22)) == 0ull, 1)) {
       const float q = (fv + fx) - fv;
-      const bool a = q > 0.5f, b = (q == 1.0f);
-      ix = 2u * v + (a ? 1u : 0u) + (b ? 1u : 0u);
-      bitx = a && !b;
+      const uint32_t a = q > 0.5f ? 1u : 0u, b = (q == 1.0f) ? 1u : 0u;
+      ix = 2u * v + a + b;
+      bitx = a & ~b;
     } else {
       const float two_cc = (float)(int32_t)((uint32_t)P.cell_count << 1);
       const float rx = __builtin_rintf(((fv + fx) * P.inv_cell_count) * two_cc + -0.5f);
       ix = (uint32_t)f2i(rx);
       const float tx = __builtin_truncf(rx);
-      bitx = (tx + -(2.0f * __builtin_floorf(tx / 2.0f))) != 0.0f;   // 0 or 1 here: rx >= 2^23 - 1
+      bitx = ((tx + -(2.0f * __builtin_floorf(tx / 2.0f))) != 0.0f) ? 1u : 0u;
+      if (v < (1u << 22)) {                           // lanes that did not need the literal form
+        const float q = (fv + fx) - fv;
+        const uint32_t a = q > 0.5f ? 1u : 0u, b = (q == 1.0f) ? 1u : 0u;
+        ix = 2u * v + a + b; bitx = a & ~b;
+      }
     }
-    const bool by = fy > 0.5f, bz = fz > 0.5f;
-    qx = (qx << 1) | (bitx ? 1u : 0u); qy = (qy << 1) | (by ? 1u : 0u); qz = (qz << 1) | (bz ? 1u : 0u);
-    const uint32_t idx = ((ix << 2) + (by ? 2u : 0u) + (bz ? 1u : 0u)) & 0x1FFFFFFFu;
-    uint32_t code;
-    if (COUNT) { cnt.level_slots += slot64(); cnt.level_active++; }
-    if (mkey && (*mkey & 0x1FFFFFFFu) == idx) {
-      v = *mval; code = *mkey >> 30;
-    } else {
-      if (COUNT) cnt.memo_miss++;
-      v = fetch_node(ns, idx, code);
-      if (mkey) { *mkey = idx | (code << 30); *mval = v; }
+    qx = (qx << 1) | bitx;
+    const uint32_t idx = ((ix << 2) + (((Yi >> sh) & 1u) << 1) + ((Zi >> sh) & 1u)) & 0x1FFFFFFFu;
+    if (COUNT) { cnt.level_slots += slot64(); cnt.level_active++; cnt.node_loads++; }
+    // LDS table first (unconditional read of a clamped index: no branch for resident nodes)
+    const uint32_t li = idx < ns.lds_nodes ? idx : 0u;
+    const uint32_t n = ns.lds[li];
+    const bool resident = (idx < ns.lds_nodes) & (n != kPackedEscape);
+    v = n >> 2; code = n & 3u;
+    if (!resident) {
+      if (mkey && (*mkey & 0x1FFFFFFFu) == idx) {
+        v = *mval; code = *mkey >> 30;
+      } else {
+        if (COUNT) cnt.memo_miss++;
+        const auto n2 = __builtin_amdgcn_raw_buffer_load_b64(ns.cells, (int)(idx << 3), 0, 0);
+        const uint32_t node_type = (uint32_t)n2[1];
+        code = (node_type == 0u) ? 0u : (node_type == 2u ? 2u : 1u);
+        v = (uint32_t)n2[0];
+        if (mkey) { *mkey = idx | (code << 30); *mval = v; }
+      }
     }
-    if (COUNT) cnt.node_loads++;
-    if (code != 1u) { is_leaf = (code == 2u); return true; }
-    const float x2 = fx + fx, y2 = fy + fy, z2 = fz + fz;
+    m = l;
+    const float x2 = fx + fx;
     fx = (fx >= 0.5f) ? x2 - 1.0f : x2;
-    fy = (fy >= 0.5f) ? y2 - 1.0f : y2;
-    fz = (fz >= 0.5f) ? z2 - 1.0f : z2;
-    return false;
   };
-  bool done = false;
 #pragma unroll
-  for (int l = 0; l < CL; l++) {
-    if (!done && l < depth) done = level(&memo.key[l], &memo.val[l]);
+  for (int l = 1; l <= kMemoFirst; l++) {
+    if (code == 1u && l <= depth) level(l, nullptr, nullptr);
   }
-  for (int l = CL; !done && l < depth; l++) done = level(nullptr, nullptr);
-  inv_pow_depth = ipd; gx = (float)qx * ipd; gy = (float)qy * ipd; gz = (float)qz * ipd; value = v;
-  return is_leaf;
+#pragma unroll
+  for (int l = kMemoFirst + 1; l <= kMemoFirst + CL; l++) {
+    if (code == 1u && l <= depth) level(l, &memo.key[l - kMemoFirst - 1], &memo.val[l - kMemoFirst - 1]);
+  }
+  for (int l = kMemoFirst + CL + 1; code == 1u && l <= depth; l++) level(l, nullptr, nullptr);
+  const float ipd = __uint_as_float((uint32_t)(127 - m) << 23);             // 2^-m = inv_pow_depth after m halvings
+  inv_pow_depth = (m == 0) ? 1.0f : ipd;
+  const int sh = depth - m;
+  gx = (float)qx * ipd; gy = (float)(Yi >> sh) * ipd; gz = (float)(Zi >> sh) * ipd;
+  if (m == 0) { gx = 0.f; gy = 0.f; gz = 0.f; }
+  value = v;
+  return code == 2u;
 }
 
 TDT_DEV float rand2(float cx, float cy) {   // Rand(vec2) rc:53
