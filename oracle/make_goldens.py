@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE shader itself (unmodified, read from
+$REF_DIR at run time) on Mesa llvmpipe through oracle/_ref/libglref.so.
+
+Run in the build container only (needs /root/reference and the swrast DRI driver):
+    make -C oracle && python oracle/make_goldens.py
+Fixtures are data: scene parameters, camera uniforms and the RGBA32F image the reference wrote.
+Scenes are regenerated from their parameters by libtdthost.so (byte-identical everywhere; a
+sha256 of every payload is stored and re-checked by the tests).
+"""
+import hashlib
+import json
+import os
+import platform
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+import oracle_py  # noqa: E402
+from tdt4230_project_raytracing_amd import host  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+# name -> (scene spec, W, H, spp, max_bounce, crop)   crop = (x0, y0, w, h) stored region or None (whole image)
+CASES = {
+    "demo_256x256_spp1_b6": (("config", 0), 256, 256, 1, 6, None),
+    "demo_160x96_spp4_b6": (("config", 0), 160, 96, 4, 6, None),
+    "demo_320x180_spp2_b3": (("config", 0), 320, 180, 2, 3, None),          # floor-div dispatch leaves rows 160..179 unwritten
+    "config1_256x256_spp1_b1": (("config", 1), 256, 256, 1, 1, None),      # BASELINE configs[0]
+    "config2_240x135_spp4_b8": (("config", 2), 240, 135, 4, 8, None),      # configs[1] scene, 1/8 resolution
+    "config2_1920x1080_spp2_b8_crop": (("config", 2), 1920, 1080, 2, 8, (896, 480, 128, 96)),   # full-size uniforms, cropped
+    "terrain7_192x108_spp2_b8": (("generate", 1, 7, 1 << 18, 200, 0x77), 192, 108, 2, 8, None),   # > LDS-table cells
+    "shells7_192x108_spp2_b8": (("generate", 2, 7, 1 << 18, 256, 0x99), 192, 108, 2, 8, None),
+    "config3_3840x2160_spp1_b16_crop": (("config", 3), 3840, 2160, 1, 16, (1856, 1000, 96, 64)),
+    "config5_1920x1080_spp1_b8_crop": (("config", 5), 1920, 1080, 1, 8, (900, 500, 96, 64)),
+}
+
+
+def make_scene(spec):
+    if spec[0] == "config":
+        return host.Scene.config(spec[1])
+    return host.Scene.generate(*spec[1:])
+
+
+def scene_digest(scene):
+    return {str(k): hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest() for k, v in sorted(scene.blobs.items())}
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    gl = oracle_py.GLRef.get()
+    flags = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                fl = set(line.split(":")[1].split())
+                flags = " ".join(sorted(fl & {"fma", "avx2", "avx512f", "sse4_1"}))
+                break
+    except OSError:
+        pass
+    meta_common = {"renderer": gl.renderer(), "cpu_flags": flags, "machine": platform.machine(),
+                   "shader": "assets/shaders/raytracer.comp (unmodified, loaded from $REF_DIR at run time)"}
+    for name, (spec, W, H, spp, bounce, crop) in CASES.items():
+        scene = make_scene(spec)
+        cam = host.camera_reference_pose(W, H, spp, bounce)
+        img = gl.render(scene, cam)                       # dispatch_compute(W+1, H+1, 1), main.rs:579
+        if crop:
+            x0, y0, w, h = crop
+            data = img[y0:y0 + h, x0:x0 + w].copy()
+        else:
+            data = img
+        meta = dict(meta_common)
+        meta.update({"scene": list(spec), "W": W, "H": H, "spp": spp, "max_bounce": bounce, "crop": crop,
+                     "scene_sha256": scene_digest(scene),
+                     "camera": {k: (list(getattr(cam, k)) if hasattr(getattr(cam, k), "__len__") else getattr(cam, k))
+                                for k, _ in host.CameraUniforms._fields_}})
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), image=data, meta=json.dumps(meta))
+        print(f"{name}: {data.shape} written px {(img[..., 3] == 1).sum()} nan {np.isnan(img).sum()}")
+
+
+def math_table():
+    """sin / cos / pow(x,5) / ... of llvmpipe on a fixed input set."""
+    rng = np.random.default_rng(0xA2B)
+    xs = np.concatenate([
+        np.linspace(0, 2 * np.pi, 1024, dtype=np.float32), np.linspace(-200, 200, 2048, dtype=np.float32),
+        rng.uniform(-2, 2, 1024).astype(np.float32), rng.uniform(-9000, 9000, 2048).astype(np.float32),
+        rng.uniform(0, 1, 2048).astype(np.float32)]).astype(np.float32)
+    tab = oracle_py.glref_math_table(xs)
+    np.savez_compressed(os.path.join(OUT, "math_table.npz"), x=xs, table=tab,
+                        columns=json.dumps(["sin", "cos", "pow5", "inversesqrt", "rcp", "sqrt", "fract", "fract_sin_43758"]))
+    print("math_table:", tab.shape)
+
+
+if __name__ == "__main__":
+    main()
+    math_table()

@@ -207,3 +207,24 @@ class GLRef:
         img = np.zeros((H, W, 4), np.float32)
         self.L.glref_image_read(img.ctypes.data)
         return (img, t) if want_time else img
+
+
+def glref_math_table(xs):
+    """Run oracle/glref/probe_math.comp (our own test shader) on llvmpipe: returns [n][8] =
+    sin, cos, pow(x,5), inversesqrt, 1/x, sqrt, fract, fract(sin(x)*43758.5453) of every input."""
+    g = GLRef.get()
+    xs = np.ascontiguousarray(xs, np.float32)
+    n = (xs.size + 63) // 64 * 64
+    xin = np.zeros(n, np.float32)
+    xin[:xs.size] = xs
+    out = np.zeros(n * 8, np.float32)
+    g.program(os.path.join(_HERE, "glref", "probe_math.comp"))
+    g.L.glref_free_buffers()
+    assert g.L.glref_ssbo(0, xin.ctypes.data, xin.nbytes) == 0
+    assert g.L.glref_ssbo(1, out.ctypes.data, out.nbytes) == 0
+    t = g.L.glref_dispatch_compute(n, 1, 1)       # floor(n / 64) groups
+    assert t >= 0
+    assert g.L.glref_ssbo_read(1, out.ctypes.data, out.nbytes) == 0
+    g._prog = None
+    g.L.glref_free_buffers()
+    return out.reshape(n, 8)[:xs.size]

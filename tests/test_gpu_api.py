@@ -1,0 +1,183 @@
+"""The C ABI on a real GPU: partition + tile buffers + assemble, progressive accumulate/resolve,
+error behaviour of the GL-wrapper stand-ins, and the committed reference renders."""
+import ctypes
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tdt4230_project_raytracing_amd import host, rt, tiles
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if "math_table" not in p)
+
+
+def _eq(a, b):
+    return (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_gpu_bit_exact_vs_reference_render(name):
+    """HIP path vs the image the reference shader itself wrote (llvmpipe), same scene and uniforms."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    spec = meta["scene"]
+    scene = host.Scene.config(spec[1]) if spec[0] == "config" else host.Scene.generate(*spec[1:])
+    cam = host.camera_reference_pose(meta["W"], meta["H"], meta["spp"], meta["max_bounce"])
+    r = rt.Renderer(scene, cam)
+    try:
+        img = r.render()
+    finally:
+        r.close()
+    if meta["crop"]:
+        x0, y0, w, h = meta["crop"]
+        img = img[y0:y0 + h, x0:x0 + w]
+    golden = z["image"]
+    eq = (img.view(np.uint32) == golden.view(np.uint32)).all(axis=2)
+    assert eq.all(), f"{int((~eq).sum())} pixels differ (max |d| {np.nanmax(np.abs(img - golden)):.3g}; tolerance of the north star: 1e-4)"
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_partition_tile_buffers_and_assemble(oracle, world):
+    """Every rank's tile buffer, gathered and de-interleaved by tdt_assemble_tiles, equals the one-rank image."""
+    import torch
+    scene = host.Scene.config(2)
+    W, H = 200, 120
+    cam = host.camera_reference_pose(W, H, 2, 6)
+    dw, dh = W + 1, H + 1
+    cw, ch = tiles.cover(W, H, dw, dh)
+    total = tiles.tile_grid(cw, ch)[2]
+    cap = tiles.tiles_per_rank(total, world)
+    ref = oracle.render(scene, cam, threads=8)
+    gathered = torch.zeros((world, cap, 32, 32, 4), dtype=torch.float32, device="cuda:0")
+    pixels = 0
+    for rank in range(world):
+        r = rt.Renderer(scene, cam, rank=rank, world=world, image_ptr=gathered[rank].data_ptr(), tile_buffer_tiles=cap)
+        try:
+            assert r.shader.owned_tiles(dw, dh) == (tiles.owned_tiles(total, rank, world), tiles.tile_grid(cw, ch)[0], total)
+            assert r.shader.covered_pixels(dw, dh) == tiles.owned_pixels(cw, ch, rank, world)
+            pixels += r.shader.covered_pixels(dw, dh)
+            r.dispatch()
+            r.ctx.finish()
+        finally:
+            r.close()
+    assert pixels == cw * ch
+    # numpy de-interleave (host arithmetic) and the HIP assemble kernel agree with the oracle
+    assert _eq(tiles.assemble(gathered.cpu().numpy(), W, H, cw, ch, world), ref)
+    full = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    r0 = rt.Renderer(scene, cam, rank=0, world=world, image_ptr=gathered[0].data_ptr(), tile_buffer_tiles=cap)
+    try:
+        tex = rt.Texture.wrap_device(r0.ctx, full.data_ptr(), W, H, bind=False)
+        r0.shader.assemble_tiles(gathered.data_ptr(), world, cap, tex, dw, dh)
+        r0.ctx.finish()
+    finally:
+        r0.close()
+    torch.cuda.synchronize()
+    assert _eq(full.cpu().numpy(), ref)
+
+
+def test_partition_into_full_size_image(oracle):
+    """With the full-size image bound, a rank writes only its own work-groups."""
+    scene = host.Scene.demo()
+    cam = host.camera_reference_pose(128, 96, 1, 4)
+    ref = oracle.render(scene, cam, threads=4)
+    acc = np.zeros_like(ref)
+    for rank in range(3):
+        r = rt.Renderer(scene, cam, rank=rank, world=3)
+        try:
+            img = r.render()
+        finally:
+            r.close()
+        mask = img[..., 3] == 1
+        assert not (acc[mask].any())                    # disjoint
+        acc[mask] = img[mask]
+    assert _eq(acc, ref)
+
+
+def test_progressive_accumulate_equals_one_pass(oracle):
+    """BASELINE configs[4] style: k passes carrying fp32 running sums (+ the shader's loop-carried
+    temporaries) in sample order, one resolve — bit-identical to a single dispatch."""
+    import torch
+    scene = host.Scene.config(2)
+    W, H, spp = 160, 96, 12
+    cam = host.camera_reference_pose(W, H, spp, 8)
+    one = oracle.render(scene, cam, threads=8)
+    accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    carry = torch.zeros((H, W, 16), dtype=torch.float32, device="cuda:0")
+    r = rt.Renderer(scene, cam, image_ptr=accum.data_ptr())
+    try:
+        for begin, count in ((0, 5), (5, 1), (6, 6)):
+            r.shader.dispatch_accumulate(W + 1, H + 1, 1, begin, count, carry.data_ptr())
+        r.shader.dispatch_resolve(W + 1, H + 1, 1, spp)
+        img = r.texture.read()
+    finally:
+        r.close()
+    assert _eq(img, one)
+
+
+def test_generic_kernel_equals_exact_comparison_kernel(oracle, monkeypatch):
+    """TDT_FORCE_GENERIC=1 runs the literal float treeLookup on a power-of-two scene: same bits."""
+    scene = host.Scene.config(2)
+    cam = host.camera_reference_pose(160, 96, 2, 8)
+    ref = oracle.render(scene, cam, threads=8)
+    monkeypatch.setenv("TDT_FORCE_GENERIC", "1")
+    r = rt.Renderer(scene, cam)
+    try:
+        assert _eq(r.render(), ref)
+    finally:
+        r.close()
+
+
+def test_zero_samples_and_zero_bounces(oracle):
+    scene = host.Scene.demo()
+    for spp, bounce in ((0, 4), (2, 0)):
+        cam = host.camera_reference_pose(64, 64, spp, bounce)
+        r = rt.Renderer(scene, cam)
+        try:
+            got = r.render()
+        finally:
+            r.close()
+        assert _eq(got, oracle.render(scene, cam)), (spp, bounce)
+
+
+def test_error_behaviour():
+    with rt.Context(0) as ctx:
+        cs = rt.ComputeShader(ctx)
+        assert cs.group_size == [32, 32, 1]                                   # compute_shader.rs:18
+        with pytest.raises(rt.TdtError) as e:
+            cs.program.set_i32("camera.no_such_uniform", 1)                   # program.rs:144-165
+        assert e.value.code == rt.ERR_VARIABLE_NOT_FOUND and "camera.no_such_uniform" in str(e.value)
+        with pytest.raises(rt.TdtError) as e:
+            cs.program.set_f32("camera.image_width", 1.0)                     # wrong type -> TypedVariableNotFound
+        assert e.value.code == rt.ERR_VARIABLE_NOT_FOUND
+        with pytest.raises(rt.TdtError) as e:
+            cs.dispatch_compute(33, 33, 1)                                    # nothing bound
+        assert e.value.code == rt.ERR_INCOMPLETE
+        with pytest.raises(rt.TdtError) as e:
+            rt.ComputeShader(ctx, rt.PROGRAM_OCTREE_UPDATE)
+        assert e.value.code == rt.ERR_INVALID_ENUM
+        vbo = rt.VertexBufferObject(ctx, np.zeros(4, np.float32))
+        with pytest.raises(rt.TdtError) as e:
+            ctx.bind_buffer_base(rt.SHADER_STORAGE_BUFFER, 9, vbo)
+        assert e.value.code == rt.ERR_INVALID_VALUE
+        with pytest.raises(rt.TdtError) as e:
+            ctx.bind_buffer_base(0x1234, 0, vbo)
+        assert e.value.code == rt.ERR_INVALID_ENUM
+        ctx.bind_buffer_base(rt.ATOMIC_COUNTER_BUFFER, 0, vbo)                # octree.rs:115: accepted, unused
+
+
+def test_out_of_range_cells_read_as_empty(oracle):
+    """Robust buffer access: the demo scene's shader divides by cell_count = 100000 but the cell
+    buffer is shorter; truncating it further must behave exactly like the oracle's zero reads."""
+    scene = host.Scene.demo()
+    scene.blobs[0] = scene.blobs[0][:19 * 16 - 6].copy()      # cut into the last cell, odd dword count
+    cam = host.camera_reference_pose(96, 96, 1, 6)
+    r = rt.Renderer(scene, cam)
+    try:
+        got = r.render()
+    finally:
+        r.close()
+    assert _eq(got, oracle.render(scene, cam, threads=4))

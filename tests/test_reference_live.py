@@ -1,0 +1,36 @@
+"""Live comparison against the reference shader on llvmpipe — only where /root/reference and the
+harness exist (the build container); skipped on the GPU box.  Complements the committed fixtures
+with freshly generated scenes."""
+import numpy as np
+import pytest
+
+from tdt4230_project_raytracing_amd import host
+
+
+@pytest.mark.parametrize("kind,depth,seed", [(0, 3, 11), (0, 4, 12), (1, 5, 13), (2, 6, 14)])
+def test_oracle_vs_reference_shader_fresh_scene(oracle, glref, kind, depth, seed):
+    scene = host.Scene.generate(kind, depth, 1 << 14, 100, seed)
+    cam = host.camera_reference_pose(96, 64, 2, 5)
+    ref = glref.render(scene, cam)
+    got = oracle.render(scene, cam, threads=4)
+    assert (got.view(np.uint32) == ref.view(np.uint32)).all()
+
+
+def test_reference_work_group_size_and_layout(glref):
+    """compute_shader.rs:18 queries {32,32,1}; the `layout(shared)` blocks are packed like std430,
+    which is what the tightly packed host payloads assume (SURVEY.md §7 hard parts)."""
+    import ctypes
+    glref.program()
+    gs = (ctypes.c_int * 3)()
+    glref.L.glref_group_size(gs)
+    assert list(gs) == [32, 32, 1]
+    expect = {b"indirect_cells[0].value": (0, 8), b"indirect_cells[0].type": (4, 8),
+              b"octree_floats[0].scale": (16, None), b"octree_floats[0].inv_scale": (20, None),
+              b"octree_floats[0].inv_cell_count": (24, None), b"octree_ints[0].max_iter": (4, None),
+              b"octree_ints[0].cell_count": (8, None), b"materials[0].albedo_index": (8, 12), b"albedos[0].z": (8, 12)}
+    for name, (off, stride) in expect.items():
+        out = (ctypes.c_int * 2)()
+        assert glref.L.glref_buffer_variable(name, out) == 0, name
+        assert out[0] == off, (name, out[0])
+        if stride is not None:
+            assert out[1] == stride, (name, out[1])
