@@ -14,7 +14,9 @@ HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc
 # -ffp-contract=off and IEEE divide/sqrt are PARITY flags, not tuning knobs: the reference's
 # arithmetic is unfused and correctly rounded (DESIGN.md "Numerics").
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-             "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wextra"]
+             "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wextra",
+             # measured: SLP-packed v_pk_*_f32 costs 6 % here (register-pair shuffles around scalar vec3 code)
+             "-fno-slp-vectorize"]
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-ffp-contract=off"]
 
 
@@ -34,7 +36,7 @@ def _run(cmd):
 
 def build_host(force=False):
     out = os.path.join(_HERE, "libtdthost.so")
-    srcs = [os.path.join(CSRC, "host_scene.cpp"), os.path.join(INCLUDE, "tdt_host.h")]
+    srcs = [os.path.join(CSRC, "host_scene.cpp"), os.path.join(INCLUDE, "tdt_host.h"), os.path.abspath(__file__)]
     if force or _newer(out, srcs):
         _run(["g++"] + HOST_FLAGS + ["-I", INCLUDE, srcs[0], "-o", out])
     return out
@@ -43,7 +45,7 @@ def build_host(force=False):
 def build_device(force=False, extra_flags=()):
     out = os.path.join(_HERE, "libtdtrt.so")
     srcs = [os.path.join(CSRC, f) for f in ("tdt_rt.hip", "trace_device.hpp", "trace_params.h")] + \
-           [os.path.join(INCLUDE, "tdt_rt.h")]
+           [os.path.join(INCLUDE, "tdt_rt.h"), os.path.abspath(__file__)]
     if force or _newer(out, srcs):
         _run([HIPCC] + HIP_FLAGS + list(extra_flags) + ["-I", INCLUDE, "-I", CSRC, srcs[0], "-o", out])
     return out

@@ -70,7 +70,7 @@ enum : int { ST_TRAVERSE = 0, ST_HIT = 1, ST_END = 2, ST_FETCH = 3, ST_PRIMARY =
 // MODE 0: the whole of main() rc:234-252.  MODE 1: only the sample loop, adding to running sums.
 // COUNT: instrumented build that also totals the events defining the algorithmic bytes.
 // POW2: exact-comparison treeLookup (see tree_lookup_pow2) vs the literal float form.
-template <int MODE, bool COUNT, bool POW2>
+template <int MODE, bool COUNT, bool POW2, int DEPTH = 0, bool RESIDENT = false, bool SAFEV = false>
 __global__ __launch_bounds__(1024) void trace_kernel(const TraceParams P) {
   __shared__ __attribute__((aligned(16))) uint32_t s_nodes[kLdsCells * 8];
   for (uint32_t i = threadIdx.x * 4u; i < P.lds_nodes; i += 1024u * 4u)
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(1024) void trace_kernel(const TraceParams P) {
         } else {
           float ugx, ugy, ugz; uint32_t value;
           if (COUNT) cnt.iterations++;
-          const bool leaf = POW2 ? tree_lookup_pow2<COUNT, kMemoLevels>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, memo, cnt)
+          const bool leaf = POW2 ? tree_lookup_pow2<COUNT, kMemoLevels, DEPTH, RESIDENT, SAFEV>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, memo, cnt)
                                  : tree_lookup<COUNT>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, cnt);
           const float bx = ugx * P.scale + P.min_x, by = ugy * P.scale + P.min_y, bz = ugz * P.scale + P.min_z;
           const float cs0 = P.scale * inv_pow_depth;
@@ -317,6 +317,22 @@ __global__ __launch_bounds__(256) void pack_cells_kernel(const uint32_t *__restr
   packed[i] = (value < (1u << 30)) ? ((value << 2) | code) : kPackedEscape;
 }
 
+// One pass over the whole cells payload: out[0] = largest PARENT value (used as a cell index),
+// out[1] = largest value of any node.  Lets the host pick the specialised lookups (SAFEV / RESIDENT).
+__global__ __launch_bounds__(256) void scan_cells_kernel(const uint32_t *__restrict__ cells, uint32_t n_nodes, uint32_t *__restrict__ out) {
+  uint32_t mp = 0, ma = 0;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_nodes; i += gridDim.x * 256u) {
+    const uint2 n = *reinterpret_cast<const uint2 *>(cells + 2u * (size_t)i);
+    ma = n.x > ma ? n.x : ma;
+    if (n.y != 0u && n.y != 2u) mp = n.x > mp ? n.x : mp;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    uint32_t a = (uint32_t)__shfl_xor((int)mp, o, 64), b = (uint32_t)__shfl_xor((int)ma, o, 64);
+    mp = a > mp ? a : mp; ma = b > ma ? b : ma;
+  }
+  if ((threadIdx.x & 63) == 0) { atomicMax(&out[0], mp); atomicMax(&out[1], ma); }
+}
+
 // De-interleave gathered per-rank tile buffers ([rank][k][32][32] RGBA) into a W x H image.
 __global__ __launch_bounds__(256) void assemble_kernel(const float4 *__restrict__ tiles, float4 *__restrict__ image,
                                                        int image_width, int cover_w, int cover_h, int tiles_x,
@@ -366,8 +382,11 @@ struct tdt_ctx {
   uint32_t *packed;             // LDS-table image of the bound cells buffer
   const tdt_buffer *packed_of;  // which buffer/version `packed` was built from
   unsigned long long packed_version;
+  uint32_t *scan;               // device scratch of scan_cells_kernel
+  uint32_t max_parent_value, max_any_value;   // its result for `packed_of`
   int num_cus;
   bool force_generic;   // TDT_FORCE_GENERIC=1: always run the literal-arithmetic kernel (A/B testing)
+  bool no_specialise;   // TDT_NO_SPECIALISE=1: never pick a scene-specialised kernel (A/B testing)
   std::vector<tdt_buffer *> buffers;
   std::vector<tdt_image *> images;
   std::vector<tdt_compute *> computes;
@@ -482,18 +501,28 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     TDT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, 32 * sizeof(unsigned long long), ctx->stream));
     P.counters = ctx->counters;
   }
+  const uint32_t buf_nodes = P.cells_dwords >> 1;
   if (t.owned > 0 && mode != 2) {
     // LDS-table image of the bound cells buffer (rebuilt only when the buffer or its contents changed)
     const tdt_buffer *cb = ctx->ssbo[TDT_SLOT_CELLS];
     if (!ctx->packed) TDT_HIP(ctx, hipMalloc((void **)&ctx->packed, (size_t)tdt::kLdsCells * 8 * sizeof(uint32_t)));
     if (!ctx->queue) TDT_HIP(ctx, hipMalloc((void **)&ctx->queue, sizeof(unsigned int)));
-    const uint32_t buf_nodes = P.cells_dwords >> 1;
     P.lds_nodes = buf_nodes < tdt::kLdsCells * 8u ? (buf_nodes & ~3u) : tdt::kLdsCells * 8u;
     if (ctx->packed_of != cb || ctx->packed_version != cb->version) {
+      if (!ctx->scan) TDT_HIP(ctx, hipMalloc((void **)&ctx->scan, 2 * sizeof(uint32_t)));
+      TDT_HIP(ctx, hipMemsetAsync(ctx->scan, 0, 2 * sizeof(uint32_t), ctx->stream));
       if (P.lds_nodes)
         hipLaunchKernelGGL(tdt::pack_cells_kernel, dim3((P.lds_nodes + 255) / 256), dim3(256), 0, ctx->stream,
                            P.cells, P.cells_dwords, ctx->packed, P.lds_nodes);
+      if (buf_nodes) {
+        unsigned nb = (buf_nodes + 255) / 256; if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(tdt::scan_cells_kernel, dim3(nb), dim3(256), 0, ctx->stream, P.cells, buf_nodes, ctx->scan);
+      }
       TDT_HIP(ctx, hipGetLastError());
+      uint32_t res[2] = {0, 0};
+      TDT_HIP(ctx, hipMemcpyAsync(res, ctx->scan, sizeof res, hipMemcpyDeviceToHost, ctx->stream));
+      TDT_HIP(ctx, hipStreamSynchronize(ctx->stream));    // once per cells buffer (version), not per frame
+      ctx->max_parent_value = res[0]; ctx->max_any_value = res[1];
       ctx->packed_of = cb; ctx->packed_version = cb->version;
     }
     P.packed = ctx->packed; P.queue = ctx->queue;
@@ -510,9 +539,24 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     const uint32_t cc = (uint32_t)P.cell_count;
     const bool pow2 = !ctx->force_generic && P.cell_count > 0 && (cc & (cc - 1)) == 0 && cc <= (1u << 22) &&
                       P.inv_cell_count == 1.0f / (float)cc && P.max_depth >= 0 && P.max_depth <= 30;
+    // scene-property specialisations of the hot kernel (see tree_lookup_pow2); every variant is bit-identical
+    const bool safev = ctx->max_parent_value < (1u << 22);
+    const bool resident = buf_nodes == P.lds_nodes && buf_nodes > 0 && (P.cells_dwords & 1u) == 0 && ctx->max_any_value < (1u << 30);
+    bool launched = false;
+    if (mode == 0 && !counts_out && pow2 && safev && !ctx->no_specialise) {
+#define TDT_SPEC(D, R) hipLaunchKernelGGL((tdt::trace_kernel<0, false, true, D, R, true>), grid, block, 0, ctx->stream, P); launched = true; break
+      if (resident) switch (P.max_depth) {
+        case 3: TDT_SPEC(3, true); case 4: TDT_SPEC(4, true); case 5: TDT_SPEC(5, true); case 6: TDT_SPEC(6, true);
+        case 7: TDT_SPEC(7, true); default: break; }
+      else switch (P.max_depth) {
+        case 6: TDT_SPEC(6, false); case 7: TDT_SPEC(7, false); case 8: TDT_SPEC(8, false); case 9: TDT_SPEC(9, false);
+        case 10: TDT_SPEC(10, false); default: break; }
+#undef TDT_SPEC
+    }
 #define TDT_LAUNCH(M, C) do { if (pow2) hipLaunchKernelGGL((tdt::trace_kernel<M, C, true>), grid, block, 0, ctx->stream, P); \
                               else hipLaunchKernelGGL((tdt::trace_kernel<M, C, false>), grid, block, 0, ctx->stream, P); } while (0)
-    if (mode == 0 && !counts_out) TDT_LAUNCH(0, false);
+    if (launched) {}
+    else if (mode == 0 && !counts_out) TDT_LAUNCH(0, false);
     else if (mode == 0) TDT_LAUNCH(0, true);
     else if (mode == 1) TDT_LAUNCH(1, false);
     else hipLaunchKernelGGL(tdt::resolve_kernel, grid4, block4, 0, ctx->stream, P);
@@ -544,9 +588,10 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
   if (!ctx) return fail(nullptr, TDT_ERR_HIP, "out of host memory");
   ctx->device = device_id;
   for (auto &s : ctx->ssbo) s = nullptr;
-  ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr; ctx->queue = nullptr; ctx->packed = nullptr; ctx->packed_of = nullptr; ctx->packed_version = 0;
+  ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr; ctx->queue = nullptr; ctx->packed = nullptr; ctx->packed_of = nullptr; ctx->packed_version = 0; ctx->scan = nullptr; ctx->max_parent_value = ctx->max_any_value = 0xFFFFFFFFu;
   { hipDeviceProp_t prop; ctx->num_cus = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
-  { const char *fg = getenv("TDT_FORCE_GENERIC"); ctx->force_generic = fg && fg[0] == '1'; }
+  { const char *fg = getenv("TDT_FORCE_GENERIC"); ctx->force_generic = fg && fg[0] == '1';
+    const char *ns_ = getenv("TDT_NO_SPECIALISE"); ctx->no_specialise = ns_ && ns_[0] == '1'; }
   if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
   else {
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -567,6 +612,7 @@ void tdt_ctx_destroy(tdt_ctx *ctx) {
   if (ctx->counters) (void)hipFree(ctx->counters);
   if (ctx->queue) (void)hipFree(ctx->queue);
   if (ctx->packed) (void)hipFree(ctx->packed);
+  if (ctx->scan) (void)hipFree(ctx->scan);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

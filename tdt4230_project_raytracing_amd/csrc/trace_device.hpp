@@ -233,10 +233,15 @@ constexpr int kMemoFirst = 3;       // levels 1..3 = cells 0..72 at most: always
 //        NEXT cell), kept.  Needs v < 2^22 so that 2s - 0.5 is exact; larger v takes the
 //        literal formula.  fx needs the float recurrence fract(2 f) (exact).
 // Coordinates: c in [0,1) on entry (OctreeHit's outside test), so f starts as c itself.
-template <bool COUNT, int CL>
+// Scene-property specialisations chosen by the host (all bit-identical to the general form):
+//   DEPTH    > 0: max_depth is this compile-time constant (digit shifts become immediates)
+//   RESIDENT    : the whole cells buffer sits in the LDS table and no node needed the escape code
+//   SAFEV       : every PARENT value in the buffer is < 2^22 (scanned once per buffer), so the
+//                 literal-formula branch for huge cell indices cannot be taken
+template <bool COUNT, int CL, int DEPTH, bool RESIDENT, bool SAFEV>
 TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float fx, float fy, float fz, float &inv_pow_depth,
                               float &gx, float &gy, float &gz, uint32_t &value, NodeMemo<CL> &memo, Counters &cnt) {
-  const int depth = P.max_depth;
+  const int depth = DEPTH > 0 ? DEPTH : P.max_depth;
   const float scale_d = __uint_as_float((uint32_t)(127 + depth) << 23);     // 2^depth
   const float Yf = fy * scale_d, Zf = fz * scale_d;                        // exact
   const float Yfl = __builtin_floorf(Yf), Zfl = __builtin_floorf(Zf);
@@ -249,7 +254,7 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
     const int sh = depth - l;
     const float fv = (float)v;
     uint32_t ix; uint32_t bitx;
-    if (__builtin_expect(__ballot(v >= (1u << 22)) == 0ull, 1)) {
+    if (SAFEV || __builtin_expect(__ballot(v >= (1u << 22)) == 0ull, 1)) {
       const float q = (fv + fx) - fv;
       const uint32_t a = q > 0.5f ? 1u : 0u, b = (q == 1.0f) ? 1u : 0u;
       ix = 2u * v + a + b;
@@ -271,8 +276,9 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
     if (COUNT) { cnt.level_slots += slot64(); cnt.level_active++; cnt.node_loads++; }
     // LDS table first (unconditional read of a clamped index: no branch for resident nodes)
     const uint32_t li = idx < ns.lds_nodes ? idx : 0u;
-    const uint32_t n = ns.lds[li];
-    const bool resident = (idx < ns.lds_nodes) & (n != kPackedEscape);
+    uint32_t n = ns.lds[li];
+    if (RESIDENT) n = idx < ns.lds_nodes ? n : 0u;      // past the end of the buffer: reads 0 = EMPTY (robust access)
+    const bool resident = RESIDENT || ((idx < ns.lds_nodes) & (n != kPackedEscape));
     v = n >> 2; code = n & 3u;
     if (!resident) {
       if (mkey && (*mkey & 0x1FFFFFFFu) == idx) {

@@ -131,6 +131,26 @@ def test_generic_kernel_equals_exact_comparison_kernel(oracle, monkeypatch):
         r.close()
 
 
+@pytest.mark.parametrize("cfg,W,H", [(2, 160, 96), (3, 128, 72)])
+def test_unspecialised_kernel_equals_specialised(oracle, monkeypatch, cfg, W, H):
+    """TDT_NO_SPECIALISE=1 keeps the run-time-depth / non-resident lookup: same bits as the
+    scene-specialised variants the dispatcher normally picks."""
+    scene = host.Scene.config(cfg)
+    cam = host.camera_reference_pose(W, H, 2, 8)
+    ref = oracle.render(scene, cam, threads=8)
+    r = rt.Renderer(scene, cam)
+    try:
+        assert _eq(r.render(), ref)
+    finally:
+        r.close()
+    monkeypatch.setenv("TDT_NO_SPECIALISE", "1")
+    r = rt.Renderer(scene, cam)
+    try:
+        assert _eq(r.render(), ref)
+    finally:
+        r.close()
+
+
 def test_zero_samples_and_zero_bounces(oracle):
     scene = host.Scene.demo()
     for spp, bounce in ((0, 4), (2, 0)):
