@@ -161,6 +161,9 @@ int tdt_dispatch_counted(tdt_compute *c, int width, int height, int depth, uint6
 /* lane-utilisation diagnostics of the last tdt_dispatch_counted of this context (32 totals; layout in
  * csrc/trace_device.hpp `Counters`); development aid */
 int tdt_debug_counters(tdt_ctx *ctx, uint64_t out[32]);
+/* exhaustive (all 2^32 inputs) check of the kernels' short correctly-rounded rcp (0) / sqrt (1) /
+ * rsq (2) forms against the IEEE expressions; *mismatches must be 0 */
+int tdt_selftest(tdt_ctx *ctx, int which, uint64_t *mismatches);
 
 #ifdef __cplusplus
 }

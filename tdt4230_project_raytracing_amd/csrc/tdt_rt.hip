@@ -19,10 +19,6 @@
 #ifndef TDT_MIN_WAVES
 #define TDT_MIN_WAVES 4
 #endif
-#ifndef TDT_EVENT_THRESHOLD
-#define TDT_EVENT_THRESHOLD 24   // lanes that must wait for scatter / new-sample code before a wave runs it
-#endif
-
 // ============================================================================ kernels ======
 namespace tdt {
 
@@ -103,6 +99,12 @@ __global__ __launch_bounds__(1024) void trace_kernel(const TraceParams P) {
   pc.root = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}; pc.leaf = pc.root; pc.root_t = 0.f;
   const int s_end = P.spp_begin + P.spp_count;
 
+  // adaptive event threshold (wave-uniform): the more traversal work a ray is, the less it pays to
+  // keep finished lanes waiting for company before running the event code.  Measured optima over
+  // the BASELINE scenes fit  threshold ~ K / (traversal steps per ray * max_depth),  K ~ 1600.
+  uint32_t w_steps = 0, w_rays = 0;
+  int threshold = P.event_threshold > 0 ? P.event_threshold : 24;
+
   for (;;) {
     // ------------------------------------------------------------ one traversal step rc:410-447
     if (state == ST_TRAVERSE) {
@@ -156,8 +158,10 @@ __global__ __launch_bounds__(1024) void trace_kernel(const TraceParams P) {
     const unsigned long long m_trav = __ballot(state == ST_TRAVERSE);
     const unsigned long long m_event = __ballot(state != ST_TRAVERSE && state != ST_DONE);
     if (m_trav == 0ull && m_event == 0ull) break;
-    // run the (long, material-divergent) event code only when enough lanes wait for it
-    if (__popcll(m_event) < TDT_EVENT_THRESHOLD && m_trav != 0ull) continue;
+    w_steps += (uint32_t)__popcll(m_trav);            // lanes that take the next traversal step
+    // run the (long, material-divergent) event code only when enough lanes wait for it (a separate
+    // threshold for scatter alone was measured: worse at every setting)
+    if (__popcll(m_event) < threshold && m_trav != 0ull) continue;
 
     if (COUNT) { cnt.event_slots += slot64(); cnt.event_active += (state != ST_TRAVERSE && state != ST_DONE); }
     if (state == ST_HIT) {                            // RayColor loop body rc:272-295
@@ -254,11 +258,18 @@ __global__ __launch_bounds__(1024) void trace_kernel(const TraceParams P) {
       loop_count = 0; ar = 1.f; ag = 1.f; ab = 1.f;
       state = ST_NEWRAY;
     }
+    w_rays += (uint32_t)__popcll(__ballot(state == ST_NEWRAY));
+    if (P.event_threshold <= 0) {
+      if (w_steps > (1u << 28)) { w_steps >>= 1; w_rays >>= 1; }
+      const float est = P.event_k * (float)w_rays / ((float)w_steps * (float)P.max_depth + 1.0f);
+      const int th = (int)est;
+      threshold = w_rays < 256u ? 24 : (th < 2 ? 2 : (th > 40 ? 40 : th));
+    }
     if (state == ST_NEWRAY) {                         // while-condition rc:271 + OctreeHit prologue rc:399-408
       if (!(loop_count < P.max_bounce)) state = ST_END;
       else {
         if (COUNT) cnt.octree_hit_calls++;
-        ix = f_rcp(r.dx); iy = f_rcp(r.dy); iz = f_rcp(r.dz);
+        q_rcp3(r.dx, r.dy, r.dz, ix, iy, iz);
         const float lx = (P.min_x + -r.ox) * ix, ly = (P.min_y + -r.oy) * iy, lz = (P.min_z + -r.oz) * iz;
         const float ux = ((P.min_x + P.scale) + -r.ox) * ix, uy = ((P.min_y + P.scale) + -r.oy) * iy,
                     uz = ((P.min_z + P.scale) + -r.oz) * iz;
@@ -333,6 +344,27 @@ __global__ __launch_bounds__(256) void scan_cells_kernel(const uint32_t *__restr
   if ((threadIdx.x & 63) == 0) { atomicMax(&out[0], mp); atomicMax(&out[1], ma); }
 }
 
+// Exhaustive check of the short correctly-rounded forms against the IEEE expressions: every one of
+// the 2^32 float bit patterns (NaN results compare equal to NaN results).  which: 0 rcp, 1 sqrt, 2 rsq.
+__global__ __launch_bounds__(256) void selftest_kernel(int which, unsigned long long *mismatches) {
+  unsigned long long bad = 0;
+  const uint32_t stride = gridDim.x * 256u;
+  uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  for (uint32_t k = 0; k < (0xFFFFFFFFu / stride) + 1u; k++, i += stride) {
+    if (k > 0 && i < stride) break;                   // wrapped
+    const float x = __uint_as_float(i);
+    float a, b;
+    if (which == 0) { a = q_rcp(x); b = 1.0f / x; }
+    else if (which == 1) { a = q_sqrt(x); b = __builtin_sqrtf(x); }
+    else if (which == 2) { a = q_rsq(x); b = 1.0f / __builtin_sqrtf(x); }
+    else { a = __builtin_amdgcn_rcpf(x); b = 1.0f / x; }      // harness check: the raw hardware seed must NOT pass
+    const bool same = (__float_as_uint(a) == __float_as_uint(b)) || (a != a && b != b);
+    bad += same ? 0u : 1u;
+  }
+  for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor((long long)bad, o, 64);
+  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(mismatches, bad);
+}
+
 // De-interleave gathered per-rank tile buffers ([rank][k][32][32] RGBA) into a W x H image.
 __global__ __launch_bounds__(256) void assemble_kernel(const float4 *__restrict__ tiles, float4 *__restrict__ image,
                                                        int image_width, int cover_w, int cover_h, int tiles_x,
@@ -386,6 +418,8 @@ struct tdt_ctx {
   uint32_t max_parent_value, max_any_value;   // its result for `packed_of`
   int num_cus;
   bool force_generic;   // TDT_FORCE_GENERIC=1: always run the literal-arithmetic kernel (A/B testing)
+  int event_threshold;  // TDT_EVENT_THRESHOLD=n fixes the event threshold (experiments); 0 = adaptive
+  float event_k;        // TDT_EVENT_K overrides the adaptive constant
   bool no_specialise;   // TDT_NO_SPECIALISE=1: never pick a scene-specialised kernel (A/B testing)
   std::vector<tdt_buffer *> buffers;
   std::vector<tdt_image *> images;
@@ -492,6 +526,8 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
   else return fail(ctx, TDT_ERR_INVALID_OPERATION,
                    "bound image is neither camera.image_width x image_height nor a 32 x 32*tiles tile buffer");
   P.spp_begin = spp_begin; P.spp_count = spp_count; P.mode = mode; P.total_spp = total_spp;
+  P.event_threshold = ctx->event_threshold;   // 0: adaptive (see trace_kernel)
+  P.event_k = ctx->event_k;
 
   TDT_HIP(ctx, hipSetDevice(ctx->device));
   if (ctx->ssbo[TDT_SLOT_CELLS]->bytes > 0xFFFFFFF8ull)
@@ -591,7 +627,9 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
   ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr; ctx->queue = nullptr; ctx->packed = nullptr; ctx->packed_of = nullptr; ctx->packed_version = 0; ctx->scan = nullptr; ctx->max_parent_value = ctx->max_any_value = 0xFFFFFFFFu;
   { hipDeviceProp_t prop; ctx->num_cus = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
   { const char *fg = getenv("TDT_FORCE_GENERIC"); ctx->force_generic = fg && fg[0] == '1';
-    const char *ns_ = getenv("TDT_NO_SPECIALISE"); ctx->no_specialise = ns_ && ns_[0] == '1'; }
+    const char *ns_ = getenv("TDT_NO_SPECIALISE"); ctx->no_specialise = ns_ && ns_[0] == '1';
+    const char *et = getenv("TDT_EVENT_THRESHOLD"); ctx->event_threshold = et ? atoi(et) : 0;
+    const char *ek = getenv("TDT_EVENT_K"); ctx->event_k = ek ? (float)atof(ek) : 1600.0f; }
   if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
   else {
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -889,6 +927,20 @@ int tdt_debug_counters(tdt_ctx *ctx, uint64_t out[32]) {
   if (!ctx || !out || !ctx->counters) return TDT_ERR_INVALID_VALUE;
   TDT_HIP(ctx, hipSetDevice(ctx->device));
   TDT_HIP(ctx, hipMemcpy(out, ctx->counters, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return TDT_OK;
+}
+
+/* Exhaustive self-test of the kernels' short correctly-rounded rcp / sqrt / rsq forms against the
+ * IEEE expressions on all 2^32 inputs; *mismatches must come back 0 (which: 0 rcp, 1 sqrt, 2 rsq). */
+int tdt_selftest(tdt_ctx *ctx, int which, uint64_t *mismatches) {
+  if (!ctx || !mismatches || which < 0 || which > 3) return TDT_ERR_INVALID_VALUE;
+  TDT_HIP(ctx, hipSetDevice(ctx->device));
+  if (!ctx->counters) TDT_HIP(ctx, hipMalloc((void **)&ctx->counters, 32 * sizeof(unsigned long long)));
+  TDT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(tdt::selftest_kernel, dim3(4096), dim3(256), 0, ctx->stream, which, ctx->counters);
+  TDT_HIP(ctx, hipGetLastError());
+  TDT_HIP(ctx, hipMemcpyAsync(mismatches, ctx->counters, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  TDT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return TDT_OK;
 }
 

@@ -19,6 +19,43 @@ namespace tdt {
 TDT_DEV float f_fract(float x) { return x - __builtin_floorf(x); }
 TDT_DEV float f_rcp(float x) { return 1.0f / x; }                          // IEEE-rounded
 TDT_DEV float f_rsq(float x) { return 1.0f / __builtin_sqrtf(x); }          // two roundings, as the reference
+
+// ---- short correctly-rounded forms -------------------------------------------------------------
+// hipcc's IEEE divide / sqrt expansions carry operand scaling for the extreme exponents
+// (v_div_scale / v_div_fmas / v_div_fixup, denormal rescue): ~11 and ~15 instructions.  Inside
+// a safe exponent window a hardware seed + fused Newton steps give the SAME correctly rounded
+// result in 3 / 5 instructions.  "Same" is not argued but checked exhaustively: tdt_selftest()
+// compares these with the IEEE expressions on all 2^32 inputs (tests/test_gpu_api.py); inputs
+// outside the window take the IEEE expression (wave-uniform branch).
+TDT_DEV bool exp_in_window(float x) {      // biased exponent in [27, 228): |x| in [2^-100, 2^101)
+  return ((__float_as_uint(x) & 0x7FFFFFFFu) - 0x0D800000u) < 0x65000000u;
+}
+TDT_DEV float rcp_core(float y) {          // RN(1/y) for y in the window
+  const float r = __builtin_amdgcn_rcpf(y);
+  const float e = __builtin_fmaf(-y, r, 1.0f);
+  return __builtin_fmaf(e, r, r);
+}
+TDT_DEV float sqrt_core(float x) {         // RN(sqrt(x)) for positive x in the window
+  const float s = __builtin_amdgcn_sqrtf(x), h = 0.5f * __builtin_amdgcn_rsqf(x);
+  return __builtin_fmaf(__builtin_fmaf(-s, s, x), h, s);     // seed + one step on the exact residual
+}
+TDT_DEV float q_rcp(float y) {
+  if (__builtin_expect(__ballot(!exp_in_window(y)) != 0ull, 0)) return 1.0f / y;
+  return rcp_core(y);
+}
+TDT_DEV void q_rcp3(float a, float b, float c, float &ra, float &rb, float &rc) {   // one guard for a vec3
+  if (__builtin_expect(__ballot(!(exp_in_window(a) && exp_in_window(b) && exp_in_window(c))) != 0ull, 0)) {
+    ra = 1.0f / a; rb = 1.0f / b; rc = 1.0f / c;
+  } else { ra = rcp_core(a); rb = rcp_core(b); rc = rcp_core(c); }
+}
+TDT_DEV float q_sqrt(float x) {
+  if (__builtin_expect(__ballot(!(exp_in_window(x) && x > 0.0f)) != 0ull, 0)) return __builtin_sqrtf(x);
+  return sqrt_core(x);
+}
+TDT_DEV float q_rsq(float x) {             // RN(1 / RN(sqrt(x))): sqrt of a window value stays in the window
+  if (__builtin_expect(__ballot(!(exp_in_window(x) && x > 0.0f)) != 0ull, 0)) return 1.0f / __builtin_sqrtf(x);
+  return rcp_core(sqrt_core(x));
+}
 // min/max where a NaN operand yields the other operand (and ties return b)
 TDT_DEV float f_min(float a, float b) { return (b != b) ? a : (a < b ? a : b); }
 TDT_DEV float f_max(float a, float b) { return (b != b) ? a : (a > b ? a : b); }
@@ -154,12 +191,12 @@ TDT_DEV void cube_hit_record(const Ray &r, float t, float cx, float cy, float cz
   nx = nx * b2f(ax >= f_max(ay, az));
   ny = ny * b2f(f_max(ax, az) < ay);
   nz = nz * b2f(f_max(ax, ay) < az);
-  float rs = f_rsq((nz * nz + ny * ny) + nx * nx);
+  float rs = q_rsq((nz * nz + ny * ny) + nx * nx);
   nx = nx * rs; ny = ny * rs; nz = nz * rs;
   bool ff = (r.dz * nz + r.dy * ny) < -(r.dx * nx);
   float flip = -2.0f * b2f(!ff) + 1.0f;
   nx = nx * flip; ny = ny * flip; nz = nz * flip;
-  rs = f_rsq((nz * nz + ny * ny) + nx * nx);
+  rs = q_rsq((nz * nz + ny * ny) + nx * nx);
   h.nx = nx * rs; h.ny = ny * rs; h.nz = nz * rs;
   h.ff = ff; h.px = px; h.py = py; h.pz = pz;
 }
@@ -335,10 +372,10 @@ TDT_DEV bool scatter(const TraceParams &P, const Ray &r, const Hit &h, Ray &out,
   out.ox = h.px; out.oy = h.py; out.oz = h.pz;
   if (COUNT) { cnt.lambertian += (type == 0); cnt.metal += (type == 1); cnt.dielectric += (type == 2); cnt.unknown += ((uint32_t)type > 2u); }
   if (type == 0) {   // ScatterLambertian rc:470-482, constructFrisvad rc:453-468, SampleGGXVNDF rc:27-49
-    float rs = f_rsq((nz * nz + ny * ny) + nx * nx);
+    float rs = q_rsq((nz * nz + ny * ny) + nx * nx);
     float mx = nx * rs, my = ny * rs, mz = nz * rs;
     bool sing = nz < -0.9999f;
-    float a = f_rcp(1.0f + nz);
+    float a = q_rcp(1.0f + nz);
     float b = -((nx * ny) * a);
     float r0x = 1.0f + -((nx * nx) * a);
     float r2y = 1.0f + -((ny * ny) * a);
@@ -357,41 +394,41 @@ TDT_DEV bool scatter(const TraceParams &P, const Ray &r, const Hit &h, Ray &out,
     p3x = p3x + d; p3y = p3y + d; p3z = p3z + d;
     float U0 = f_fract((p3x + p3y) * p3z), U1 = f_fract((p3x + p3z) * p3y);
     float sx = vx * 0.85f, sy = vy * 0.85f;
-    rs = f_rsq((vz * vz + sy * sy) + sx * sx);
+    rs = q_rsq((vz * vz + sy * sy) + sx * sx);
     float va = sx * rs, vb = sy * rs, vc = vz * rs;      // Vh = (-va,-vb,-vc)
     float vhz = -vc;
     float lensq = va * va + vb * vb;
     bool nzl = 0.0f < lensq;
-    float rl = f_rsq(lensq);
+    float rl = q_rsq(lensq);
     float t1x = nzl ? vb * rl : 1.0f;
     float t1y = nzl ? -(va * rl) : 0.0f;
-    float rr = __builtin_sqrtf(U0);
+    float rr = q_sqrt(U0);
     float phi = (2.0f * 3.14159265358f) * U1;
     float sn, cs; sincos_poly(phi, sn, cs);
     float t1 = rr * cs, t2 = rr * sn;
     float s = 0.5f * (1.0f + vhz);
     float om = 1.0f + -(t1 * t1);
-    t2 = (1.0f + -s) * __builtin_sqrtf(om) + s * t2;
+    t2 = (1.0f + -s) * q_sqrt(om) + s * t2;
     float T2x = vc * t1y;
     float T2yn = vc * t1x;
     float T2z = -(va * t1y) + vb * t1x;
     float nhx = t1 * t1x + t2 * T2x;
     float nhy = t1 * t1y + -(T2yn * t2);
     float nhz = t2 * T2z;
-    float sq = __builtin_sqrtf(f_max(om + -(t2 * t2), 0.0f));
+    float sq = q_sqrt(f_max(om + -(t2 * t2), 0.0f));
     nhx = nhx + -(va * sq); nhy = nhy + -(vb * sq); nhz = nhz + -(vc * sq);
     float ex = 0.85f * nhx, ey = 0.85f * nhy, ez = f_max(nhz, 0.0f);
-    rs = f_rsq((ez * ez + ey * ey) + ex * ex);
+    rs = q_rsq((ez * ez + ey * ey) + ex * ex);
     ex = ex * rs; ey = ey * rs; ez = ez * rs;
     float dt = ((ez * dz + ey * dy) + ex * dx) * 2.0f;
     float qx = nx + (dx + -(dt * ex)), qy = ny + (dy + -(dt * ey)), qz = nz + (dz + -(dt * ez));
-    rs = f_rsq((qz * qz + qy * qy) + qx * qx);
+    rs = q_rsq((qz * qz + qy * qy) + qx * qx);
     out.dx = qx * rs; out.dy = qy * rs; out.dz = qz * rs;
     load_albedo(P, mo, ar, ag, ab);
     return true;
   }
   if (type == 1) {   // ScatterMetal rc:484-491, RandInHemisphere rc:106-115 (one cube sample, as compiled)
-    float rs = f_rsq((nz * nz + ny * ny) + nx * nx);
+    float rs = q_rsq((nz * nz + ny * ny) + nx * nx);
     float mx = nx * rs, my = ny * rs, mz = nz * rs;
     float dt = ((mz * dz + my * dy) + mx * dx) * 2.0f;
     float rx = dx + -(dt * mx), ry = dy + -(dt * my), rz = dz + -(dt * mz);
@@ -403,7 +440,7 @@ TDT_DEV bool scatter(const TraceParams &P, const Ray &r, const Hit &h, Ray &out,
     bool same = -(hz * nz + hy * ny) < hx * nx;
     if (!same) { hx = -hx; hy = -hy; hz = -hz; }
     float qx = rx + fuzz * hx, qy = ry + fuzz * hy, qz = rz + fuzz * hz;
-    rs = f_rsq((qz * qz + qy * qy) + qx * qx);
+    rs = q_rsq((qz * qz + qy * qy) + qx * qx);
     qx = qx * rs; qy = qy * rs; qz = qz * rs;
     out.dx = qx; out.dy = qy; out.dz = qz;
     load_albedo(P, mo, ar, ag, ab);
@@ -412,10 +449,10 @@ TDT_DEV bool scatter(const TraceParams &P, const Ray &r, const Hit &h, Ray &out,
   if (type == 2) {   // ScatterDielectric rc:499-522, reflectance rc:494-497
     uint32_t at = ld_dw(P.materials, P.materials_dwords, mo + 4u);
     float ir = __uint_as_float(ld_dw(P.dielectric, P.dielectric_dwords, at << 2));
-    float ratio = h.ff ? f_rcp(ir) : ir;
+    float ratio = h.ff ? q_rcp(ir) : ir;
     float pz_ = dz * nz, py_ = dy * ny, px_ = dx * nx;
     float cos_t = f_min((-pz_ + -py_) + -px_, 1.0f);
-    float sin_t = __builtin_sqrtf(1.0f + -(cos_t * cos_t));
+    float sin_t = q_sqrt(1.0f + -(cos_t * cos_t));
     bool cannot = 1.0f < ratio * sin_t;
     float q = (1.0f + -ratio) / (1.0f + ratio);
     float r0 = q * q;
@@ -429,11 +466,11 @@ TDT_DEV bool scatter(const TraceParams &P, const Ray &r, const Hit &h, Ray &out,
     } else {
       float k = 1.0f + -(ratio * (ratio * (1.0f + -(dn * dn))));
       if (!(k < 0.0f)) {
-        float m = ratio * dn + __builtin_sqrtf(k);
+        float m = ratio * dn + q_sqrt(k);
         ox_ = ratio * dx + -(m * nx); oy_ = ratio * dy + -(m * ny); oz_ = ratio * dz + -(m * nz);
       } else { ox_ = 0.0f; oy_ = 0.0f; oz_ = 0.0f; }
     }
-    float rs = f_rsq((oz_ * oz_ + oy_ * oy_) + ox_ * ox_);
+    float rs = q_rsq((oz_ * oz_ + oy_ * oy_) + ox_ * ox_);
     out.dx = ox_ * rs; out.dy = oy_ * rs; out.dz = oz_ * rs;
     ar = 1.0f; ag = 1.0f; ab = 1.0f;
     return true;
@@ -456,7 +493,7 @@ TDT_DEV Ray primary_ray(const TraceParams &P, int px, int py, int s) {
   float rx = (P.hor[0] * u + P.llc[0]) + (v * P.ver[0] + -P.org[0]);
   float ry = (P.hor[1] * u + P.llc[1]) + (v * P.ver[1] + -P.org[1]);
   float rz = (P.hor[2] * u + P.llc[2]) + (v * P.ver[2] + -P.org[2]);
-  float rs = f_rsq((rz * rz + ry * ry) + rx * rx);
+  float rs = q_rsq((rz * rz + ry * ry) + rx * rx);
   Ray r = { P.org[0], P.org[1], P.org[2], rx * rs, ry * rs, rz * rs };
   return r;
 }

@@ -60,6 +60,7 @@ SYMBOLS = [
     ("tdt_assemble_tiles", _I, [_P, _P, _I, _I, _P, _I, _I, _I]),
     ("tdt_dispatch_counted", _I, [_P, _I, _I, _I, ctypes.POINTER(ctypes.c_uint64)]),
     ("tdt_debug_counters", _I, [_P, ctypes.POINTER(ctypes.c_uint64)]),
+    ("tdt_selftest", _I, [_P, _I, ctypes.POINTER(ctypes.c_uint64)]),
 ]
 
 _lib = None
@@ -110,6 +111,12 @@ class Context:
     def bind_buffer_base(self, target, slot, vbo):
         """gl::BindBufferBase(target, slot, vbo.id()) — main.rs:352,383,408,430,448; octree.rs:67,98,115,144."""
         self.check(lib().tdt_bind_buffer_base(self.h, target, slot, vbo.h if vbo is not None else None))
+
+    def selftest(self, which):
+        """Mismatches of the short rcp (0) / sqrt (1) / rsq (2) forms vs IEEE over all 2^32 inputs."""
+        n = ctypes.c_uint64(0)
+        self.check(lib().tdt_selftest(self.h, which, ctypes.byref(n)))
+        return n.value
 
     def close(self):
         if self.h:
