@@ -68,8 +68,8 @@ enum : int { ST_TRAVERSE = 0, ST_HIT = 1, ST_END = 2, ST_FETCH = 3, ST_PRIMARY =
 // POW2: exact-comparison treeLookup (see tree_lookup_pow2) vs the literal float form.
 template <int MODE, bool COUNT, bool POW2, int DEPTH = 0, bool RESIDENT = false, bool SAFEV = false>
 __global__ __launch_bounds__(1024) void trace_kernel(const TraceParams P) {
-  __shared__ __attribute__((aligned(16))) uint32_t s_nodes[kLdsCells * 8];
-  for (uint32_t i = threadIdx.x * 4u; i < P.lds_nodes; i += 1024u * 4u)
+  __shared__ __attribute__((aligned(16))) uint16_t s_nodes[kLdsCells * 8];
+  for (uint32_t i = threadIdx.x * 8u; i < P.lds_nodes; i += 1024u * 8u)      // one cell (8 x u16) per lane and trip
     *reinterpret_cast<uint4 *>(&s_nodes[i]) = *reinterpret_cast<const uint4 *>(&P.packed[i]);
   __syncthreads();
   NodeSource ns;
@@ -319,13 +319,13 @@ __global__ __launch_bounds__(256) void resolve_kernel(const TraceParams P) {
 
 // Re-encode the first n nodes of the cells payload as one dword each for the LDS table (NodeSource).
 __global__ __launch_bounds__(256) void pack_cells_kernel(const uint32_t *__restrict__ cells, uint32_t cells_dwords,
-                                                        uint32_t *__restrict__ packed, uint32_t n_nodes) {
+                                                        uint16_t *__restrict__ packed, uint32_t n_nodes) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n_nodes) return;
   uint32_t value = 0, type = 0;
   if (2u * i + 1u < cells_dwords) { value = cells[2u * i]; type = cells[2u * i + 1u]; }   // 8-byte granules, as fetch_node
   const uint32_t code = (type == 0u) ? 0u : (type == 2u ? 2u : 1u);
-  packed[i] = (value < (1u << 30)) ? ((value << 2) | code) : kPackedEscape;
+  packed[i] = (uint16_t)((value <= kPackedMaxValue) ? ((value << 2) | code) : kPackedEscape);
 }
 
 // One pass over the whole cells payload: out[0] = largest PARENT value (used as a cell index),
@@ -411,7 +411,7 @@ struct tdt_ctx {
   tdt_image *image0;
   unsigned long long *counters;
   unsigned int *queue;          // pixel-queue head
-  uint32_t *packed;             // LDS-table image of the bound cells buffer
+  uint16_t *packed;             // LDS-table image of the bound cells buffer
   const tdt_buffer *packed_of;  // which buffer/version `packed` was built from
   unsigned long long packed_version;
   uint32_t *scan;               // device scratch of scan_cells_kernel
@@ -541,9 +541,9 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
   if (t.owned > 0 && mode != 2) {
     // LDS-table image of the bound cells buffer (rebuilt only when the buffer or its contents changed)
     const tdt_buffer *cb = ctx->ssbo[TDT_SLOT_CELLS];
-    if (!ctx->packed) TDT_HIP(ctx, hipMalloc((void **)&ctx->packed, (size_t)tdt::kLdsCells * 8 * sizeof(uint32_t)));
+    if (!ctx->packed) TDT_HIP(ctx, hipMalloc((void **)&ctx->packed, (size_t)tdt::kLdsCells * 8 * sizeof(uint16_t)));
     if (!ctx->queue) TDT_HIP(ctx, hipMalloc((void **)&ctx->queue, sizeof(unsigned int)));
-    P.lds_nodes = buf_nodes < tdt::kLdsCells * 8u ? (buf_nodes & ~3u) : tdt::kLdsCells * 8u;
+    P.lds_nodes = buf_nodes < tdt::kLdsCells * 8u ? (buf_nodes & ~7u) : tdt::kLdsCells * 8u;
     if (ctx->packed_of != cb || ctx->packed_version != cb->version) {
       if (!ctx->scan) TDT_HIP(ctx, hipMalloc((void **)&ctx->scan, 2 * sizeof(uint32_t)));
       TDT_HIP(ctx, hipMemsetAsync(ctx->scan, 0, 2 * sizeof(uint32_t), ctx->stream));
@@ -577,7 +577,7 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
                       P.inv_cell_count == 1.0f / (float)cc && P.max_depth >= 0 && P.max_depth <= 30;
     // scene-property specialisations of the hot kernel (see tree_lookup_pow2); every variant is bit-identical
     const bool safev = ctx->max_parent_value < (1u << 22);
-    const bool resident = buf_nodes == P.lds_nodes && buf_nodes > 0 && (P.cells_dwords & 1u) == 0 && ctx->max_any_value < (1u << 30);
+    const bool resident = buf_nodes == P.lds_nodes && buf_nodes > 0 && (P.cells_dwords & 1u) == 0 && ctx->max_any_value <= tdt::kPackedMaxValue;
     bool launched = false;
     if (mode == 0 && !counts_out && pow2 && safev && !ctx->no_specialise) {
 #define TDT_SPEC(D, R) hipLaunchKernelGGL((tdt::trace_kernel<0, false, true, D, R, true>), grid, block, 0, ctx->stream, P); launched = true; break

@@ -133,16 +133,17 @@ TDT_DEV uint32_t ld_dw(const uint32_t *buf, uint32_t dwords, uint32_t byte_off) 
 
 // ---- octree node fetch ----------------------------------------------------------------------
 // The first kLdsCells cells of the breadth-first cell array (= the top levels of the tree, or the
-// whole tree for a 64^3 scene) are staged in LDS by every block, one dword per node
-// (value << 2 | code; code 0 EMPTY, 1 PARENT / any other type, 2 LEAF; 0xFFFFFFFF = value does not
-// fit, read the original).  Everything else comes from the linearised octree in HBM / L2 through
+// whole tree for a 64^3 scene) are staged in LDS by every block, 16 bits per node
+// (value << 2 | code; code 0 EMPTY, 1 PARENT / any other type, 2 LEAF; 0xFFFF = value does not
+// fit in 14 bits, read the original).  Everything else comes from the linearised octree in HBM / L2 through
 // a raw buffer descriptor whose range check IS the reference's robust-access rule (reads past the
 // end return 0), so there is no bounds branch.
-constexpr uint32_t kLdsCells = 4608;                 // 4608 cells * 8 nodes * 4 B = 147,456 B of the 160 KiB LDS
-constexpr uint32_t kPackedEscape = 0xFFFFFFFFu;
+constexpr uint32_t kLdsCells = 5120;                 // 5120 cells * 8 nodes * 2 B = 81,920 B of the 160 KiB LDS
+constexpr uint32_t kPackedEscape = 0xFFFFu;
+constexpr uint32_t kPackedMaxValue = 0x3FFEu;        // largest value an LDS entry can hold
 
 struct NodeSource {
-  const uint32_t *lds;                                // LDS table
+  const uint16_t *lds;                                // LDS table
   uint32_t lds_nodes;                                 // valid entries
   __amdgpu_buffer_rsrc_t cells;                       // raw buffer over the cells payload (8-byte granules)
 };

@@ -22,7 +22,7 @@ struct TraceParams {
   float *carry;
   unsigned long long *counters; // instrumented launches only: event totals (see Counters)
   unsigned int *queue;          // global pixel queue head (zeroed before every launch)
-  const uint32_t *packed;       // cells [0, lds_cells) re-encoded as one dword per node: value << 2 | code
+  const uint16_t *packed;       // cells [0, lds_cells) re-encoded as 16 bits per node: value << 2 | code
   uint32_t lds_nodes;           // number of nodes (8 per cell) staged in LDS by every block
   int32_t compact;             // 1: image is this rank's tile buffer [owned tile k][32][32] RGBA
   int32_t cover_w, cover_h;    // pixels a dispatch covers: min(32*groups, image size)
