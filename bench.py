@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="N>1: weak = N x the pixel rows over the same frustum (per-GPU work fixed); strong = same image")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N>1 code path (tile buffer, RCCL gather, de-interleave) even with one rank: a self-test")
     args = ap.parse_args()
 
     import numpy as np
@@ -57,8 +59,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the trace has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_dist
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     W, H, spp, bounce, desc = WORKLOADS[args.config]
@@ -76,7 +80,7 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
         full = torch.zeros((IH, IW, 4), dtype=torch.float32, device=dev) if rank == 0 else None
-        if world == 1:
+        if not sharded:
             r = rt.Renderer(scene, cam, device=local_rank, stream=stream.cuda_stream, image_ptr=full.data_ptr())
             tiles_per_rank = 0
             tile_buf = gathered = full_tex = None
@@ -91,7 +95,7 @@ def main():
             gathered = torch.zeros((world, tiles_per_rank, 32, 32, 4), dtype=torch.float32, device=dev) if rank == 0 else None
             full_tex = rt.Texture.wrap_device(r.ctx, full.data_ptr(), IW, IH, bind=False) if rank == 0 else None
     my_pixels = r.shader.covered_pixels(dw, dh)
-    if world > 1:
+    if sharded:
         assert r.shader.owned_tiles(dw, dh)[0] <= tiles_per_rank
 
     ev_pairs = []
@@ -105,14 +109,14 @@ def main():
             if timed:
                 e1.record(stream)
                 ev_pairs.append((e0, e1))
-            if world > 1:
+            if sharded:
                 glist = list(gathered.unbind(0)) if rank == 0 else None
                 dist.gather(tile_buf, glist, dst=0)
                 if rank == 0:
                     r.shader.assemble_tiles(gathered.data_ptr(), world, tiles_per_rank, full_tex, dw, dh)
 
     def fence():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -125,7 +129,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt, float(my_pixels)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if sharded:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = tt.clone()
@@ -167,7 +171,7 @@ def main():
         import oracle_py
         orc = oracle_py.Oracle()
         cores = min(os.cpu_count() or 1, 32)
-        bands, band_rows = 16, 8
+        bands, band_rows = 96, 8
         ys = [int(i * (IH - 32) / bands) // 8 * 8 for i in range(bands)]
         img = np.zeros((IH, IW, 4), np.float32)
         t0 = time.perf_counter()
@@ -196,13 +200,13 @@ def main():
                        "image": [IW, IH], "dispatch": [dw, dh, 1], "written_pixels": int(total_pixels), "spp": spp,
                        "max_bounce": bounce, "octree_max_depth": scene.max_depth, "octree_cells": scene.counts["cells"],
                        "scene_bytes": scene.nbytes(),
-                       "partition": f"32x32 work-groups dealt round-robin over {world} rank(s)" + ("; one RCCL gather + de-interleave per step" if world > 1 else "")},
+                       "partition": f"32x32 work-groups dealt round-robin over {world} rank(s)" + ("; one RCCL gather + de-interleave per step" if sharded else "")},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out), flush=True)
     r.close()
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 
