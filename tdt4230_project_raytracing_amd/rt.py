@@ -73,6 +73,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
                                "the trace has no CPU fallback")
+        # One HIP runtime per process: PyTorch bundles its own libamdhip64; if ours (from /opt/rocm) were
+        # loaded first, torch would later find "no HIP GPUs".  Importing torch first makes both share one.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             f = getattr(L, name)

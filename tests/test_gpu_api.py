@@ -53,6 +53,7 @@ def test_partition_tile_buffers_and_assemble(oracle, world):
     cap = tiles.tiles_per_rank(total, world)
     ref = oracle.render(scene, cam, threads=8)
     gathered = torch.zeros((world, cap, 32, 32, 4), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()          # torch fills on its own stream; the contexts below launch on theirs
     pixels = 0
     for rank in range(world):
         r = rt.Renderer(scene, cam, rank=rank, world=world, image_ptr=gathered[rank].data_ptr(), tile_buffer_tiles=cap)
@@ -68,6 +69,7 @@ def test_partition_tile_buffers_and_assemble(oracle, world):
     # numpy de-interleave (host arithmetic) and the HIP assemble kernel agree with the oracle
     assert _eq(tiles.assemble(gathered.cpu().numpy(), W, H, cw, ch, world), ref)
     full = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
     r0 = rt.Renderer(scene, cam, rank=0, world=world, image_ptr=gathered[0].data_ptr(), tile_buffer_tiles=cap)
     try:
         tex = rt.Texture.wrap_device(r0.ctx, full.data_ptr(), W, H, bind=False)
@@ -107,6 +109,7 @@ def test_progressive_accumulate_equals_one_pass(oracle):
     one = oracle.render(scene, cam, threads=8)
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
     carry = torch.zeros((H, W, 16), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
     r = rt.Renderer(scene, cam, image_ptr=accum.data_ptr())
     try:
         for begin, count in ((0, 5), (5, 1), (6, 6)):
