@@ -37,7 +37,20 @@ CASES = {
     "shells7_192x108_spp2_b8": (("generate", 2, 7, 1 << 18, 256, 0x99), 192, 108, 2, 8, None),
     "config3_3840x2160_spp1_b16_crop": (("config", 3), 3840, 2160, 1, 16, (1856, 1000, 96, 64)),
     "config5_1920x1080_spp1_b8_crop": (("config", 5), 1920, 1080, 1, 8, (900, 500, 96, 64)),
+    # cameras OUTSIDE / on the boundary of the octree: root-test misses, stale out-parameter records, NaN-free edge paths
+    "demo_outside_side_160x96_spp3_b6": (("config", 0), 160, 96, 3, 6, None, (-1.2, 0.0, -0.5)),
+    "config2_on_boundary_160x96_spp3_b6": (("config", 2), 160, 96, 3, 6, None, (0.0, -0.1, 0.0)),
+    "config1_outside_corner_160x96_spp3_b6": (("config", 1), 160, 96, 3, 6, None, (0.5, 0.5, 0.0)),
+    "config2_outside_front_160x96_spp3_b6": (("config", 2), 160, 96, 3, 6, None, (0.1, 0.05, 0.6)),
 }
+
+
+def make_camera(W, H, spp, bounce, origin=None):
+    if origin is None:
+        return host.camera_reference_pose(W, H, spp, bounce)
+    aspect = float(np.float32(W) / np.float32(H))
+    return host.camera_build(90.0, W, aspect_ratio=aspect, viewport_height=2.0, origin=origin,
+                             samples_per_pixel=spp, max_bounce=bounce)
 
 
 def make_scene(spec):
@@ -64,9 +77,11 @@ def main():
         pass
     meta_common = {"renderer": gl.renderer(), "cpu_flags": flags, "machine": platform.machine(),
                    "shader": "assets/shaders/raytracer.comp (unmodified, loaded from $REF_DIR at run time)"}
-    for name, (spec, W, H, spp, bounce, crop) in CASES.items():
+    for name, case in CASES.items():
+        spec, W, H, spp, bounce, crop = case[:6]
+        origin = case[6] if len(case) > 6 else None
         scene = make_scene(spec)
-        cam = host.camera_reference_pose(W, H, spp, bounce)
+        cam = make_camera(W, H, spp, bounce, origin)
         img = gl.render(scene, cam)                       # dispatch_compute(W+1, H+1, 1), main.rs:579
         if crop:
             x0, y0, w, h = crop
@@ -74,7 +89,7 @@ def main():
         else:
             data = img
         meta = dict(meta_common)
-        meta.update({"scene": list(spec), "W": W, "H": H, "spp": spp, "max_bounce": bounce, "crop": crop,
+        meta.update({"scene": list(spec), "W": W, "H": H, "spp": spp, "max_bounce": bounce, "crop": crop, "origin": origin,
                      "scene_sha256": scene_digest(scene),
                      "camera": {k: (list(getattr(cam, k)) if hasattr(getattr(cam, k), "__len__") else getattr(cam, k))
                                 for k, _ in host.CameraUniforms._fields_}})

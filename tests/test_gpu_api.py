@@ -12,6 +12,15 @@ from tdt4230_project_raytracing_amd import host, rt, tiles
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _camera(meta):
+    """main.rs:165-168's camera for the fixture's size, optionally moved to the fixture's origin."""
+    if meta.get("origin") is None:
+        return host.camera_reference_pose(meta["W"], meta["H"], meta["spp"], meta["max_bounce"])
+    aspect = float(np.float32(meta["W"]) / np.float32(meta["H"]))
+    return host.camera_build(90.0, meta["W"], aspect_ratio=aspect, viewport_height=2.0, origin=meta["origin"],
+                             samples_per_pixel=meta["spp"], max_bounce=meta["max_bounce"])
 CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if "math_table" not in p)
 
 
@@ -26,7 +35,7 @@ def test_gpu_bit_exact_vs_reference_render(name):
     meta = json.loads(str(z["meta"]))
     spec = meta["scene"]
     scene = host.Scene.config(spec[1]) if spec[0] == "config" else host.Scene.generate(*spec[1:])
-    cam = host.camera_reference_pose(meta["W"], meta["H"], meta["spp"], meta["max_bounce"])
+    cam = _camera(meta)
     r = rt.Renderer(scene, cam)
     try:
         img = r.render()
