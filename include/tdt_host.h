@@ -74,6 +74,34 @@ const void *tdt_scene_blob(const tdt_scene *s, int slot, size_t *bytes);
 int tdt_scene_counts(const tdt_scene *s, int64_t out[6]);
 const char *tdt_host_last_error(void);
 
+/* ---------------------------------------------------------------- scene ingest --- */
+/* ply_point_loader::from_resources (src/utility/ply_point_loader.rs:102-319) restated over a byte
+ * buffer: the MagicaVoxel ASCII point export ("float" x y z that are really integers, uchar r g b).
+ * strict_crlf = 1 is the reference grammar to the byte ("ply\r\n", "format ascii 1.0\r\n", every
+ * line CRLF: :121,:130,:158,:175,:207,:312-314); 0 also accepts LF-only files (as checked out on
+ * Linux).  Quirks kept: a header word only has to match a PREFIX of its keyword (:138-152); the
+ * albedo key is recomputed and inserted after EVERY property of a vertex (:300-307), so the palette
+ * also holds the partial colours (0,0,0), (r,0,0), (r,g,0); the Cantor pairing runs in f64 and
+ * saturates to u32 (:228-241); the vertex count of the header is not checked against the data.
+ * One deviation: an unknown header keyword is an error here (the reference loops forever, :136-153).
+ * PARITY UNPINNED: the Rust loader cannot be built or run in this image; tests pin the restatement
+ * against hand-derived values for the reference's own 3x3x3 model. */
+typedef struct tdt_ply tdt_ply;
+int tdt_ply_parse(const void *data, size_t bytes, int strict_crlf, tdt_ply **out);
+void tdt_ply_destroy(tdt_ply *p);
+/* header.vertex, number of voxels read, min_point (:221), palette size */
+int tdt_ply_info(const tdt_ply *p, int64_t *header_vertex, int64_t *n_voxels, int32_t min_point[3], int64_t *n_albedos);
+/* 4 x i32 per voxel: x, y, z, albedo_key (as u32 bits) */
+const int32_t *tdt_ply_voxels(const tdt_ply *p);
+/* palette sorted by key (the reference's HashMap has no order): returns the number written */
+int64_t tdt_ply_albedos(const tdt_ply *p, uint32_t *keys, uint8_t *rgb, int64_t capacity);
+/* The step the reference never wrote (the loader's result is unused: main.rs:218-224): voxels ->
+ * breadth-first indirect cells + one Lambertian material per distinct voxel colour (rgb / 255).
+ * The grid edge is the next power of two >= the model's extent; z_up = 1 maps the file's z to the
+ * octree's y (MagicaVoxel is z-up); the model is centred in x, stands on the floor and is pushed to
+ * the far (z = 0) side of the octree so that the reference camera (main.rs:165-168) looks at it. */
+int tdt_scene_from_ply(const tdt_ply *p, int max_iter, int z_up, tdt_scene **out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,9 @@ CASES = {
     "config2_on_boundary_160x96_spp3_b6": (("config", 2), 160, 96, 3, 6, None, (0.0, -0.1, 0.0)),
     "config1_outside_corner_160x96_spp3_b6": (("config", 1), 160, 96, 3, 6, None, (0.5, 0.5, 0.0)),
     "config2_outside_front_160x96_spp3_b6": (("config", 2), 160, 96, 3, 6, None, (0.1, 0.05, 0.6)),
+    # the reference's own MagicaVoxel model (assets/models/monu1_point.ply, 156 942 voxels) through the PLY loader
+    # restatement and the octree builder; the built payloads (14 KB compressed) are stored in the fixture
+    "monu1_ply_320x240_spp2_b6": (("ply", "monu1_point.ply"), 320, 240, 2, 6, None),
 }
 
 
@@ -56,6 +59,9 @@ def make_camera(W, H, spp, bounce, origin=None):
 def make_scene(spec):
     if spec[0] == "config":
         return host.Scene.config(spec[1])
+    if spec[0] == "ply":
+        path = os.path.join(oracle_py.REF_DIR, "assets", "models", spec[1])
+        return host.Ply(open(path, "rb").read(), strict_crlf=False).to_scene(max_iter=256)
     return host.Scene.generate(*spec[1:])
 
 
@@ -93,7 +99,8 @@ def main():
                      "scene_sha256": scene_digest(scene),
                      "camera": {k: (list(getattr(cam, k)) if hasattr(getattr(cam, k), "__len__") else getattr(cam, k))
                                 for k, _ in host.CameraUniforms._fields_}})
-        np.savez_compressed(os.path.join(OUT, name + ".npz"), image=data, meta=json.dumps(meta))
+        extra = {f"blob_{k}": v for k, v in scene.blobs.items()} if spec[0] == "ply" else {}
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), image=data, meta=json.dumps(meta), **extra)
         print(f"{name}: {data.shape} written px {(img[..., 3] == 1).sum()} nan {np.isnan(img).sum()}")
 
 

@@ -8,9 +8,11 @@
 #include "tdt_host.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
@@ -256,6 +258,152 @@ void gen_shells(Grid &g, tdt_scene &s, uint64_t seed) {
 
 }  // namespace
 
+// ------------------------------------------------------------------ PLY point loader -------
+
+struct tdt_ply {
+  int64_t header_vertex = 0;
+  std::vector<int> prop_id;        // 0..5 = x y z r g b   (Identifier, ply_point_loader.rs:52-59)
+  std::vector<int> prop_is_pos;    // Type::Pos / Type::Uchar (:62-65)
+  std::vector<int32_t> voxels;     // x, y, z, key
+  std::map<uint32_t, std::array<uint8_t, 3>> albedos;
+  int32_t min_point[3] = {INT32_MAX, INT32_MAX, INT32_MAX};   // :221
+};
+
+namespace {
+
+// mod ply_reader (:321-339)
+constexpr uint8_t CR = 0x0D, NL = 0x0A, SPACE = 0x20;
+// expect(): index of the first mismatch over the ZIPPED (shorter) length, or -1 (None)
+int64_t ply_expect(const char *expected, const uint8_t *b, size_t n) {
+  for (size_t i = 0; expected[i] != 0 && i < n; i++)
+    if (static_cast<uint8_t>(expected[i]) != b[i]) return static_cast<int64_t>(i);
+  return -1;
+}
+int64_t seek_end_of_line(const uint8_t *b, size_t n) {
+  for (size_t i = 0; i < n; i++) if (b[i] == CR || b[i] == NL) return static_cast<int64_t>(i);
+  return -1;
+}
+int64_t seek_end_word(const uint8_t *b, size_t n) {
+  for (size_t i = 0; i < n; i++) if (b[i] == SPACE || b[i] == CR || b[i] == NL) return static_cast<int64_t>(i);
+  return -1;
+}
+// str::parse::<i64>() on ASCII: optional sign, at least one digit, nothing else; range-checked by the caller
+bool parse_int(const uint8_t *b, size_t n, int64_t lo, int64_t hi, bool allow_minus, int64_t &out) {
+  size_t i = 0; bool neg = false;
+  if (n == 0) return false;
+  if (b[0] == '+') i = 1; else if (b[0] == '-') { if (!allow_minus) return false; neg = true; i = 1; }
+  if (i >= n) return false;
+  int64_t v = 0;
+  for (; i < n; i++) {
+    if (b[i] < '0' || b[i] > '9') return false;
+    v = v * 10 + (b[i] - '0');
+    if (v > (int64_t{1} << 40)) return false;
+  }
+  v = neg ? -v : v;
+  if (v < lo || v > hi) return false;
+  out = v;
+  return true;
+}
+// cantor_pair (:228-241): f64 arithmetic, `as u32` saturates
+uint32_t cantor_pair(uint8_t a, uint8_t b, uint8_t c) {
+  const double fa = a, fb = b, fc = c;
+  const double fd = 0.5 * (fa + fb) * (fa + fb + 1.0) + fb;
+  const double hash = 0.5 * (fd + fc) * (fd + fc + 1.0) + fc;
+  return hash >= 4294967295.0 ? 0xFFFFFFFFu : static_cast<uint32_t>(hash);
+}
+
+bool ply_fail(const char *what, const char *state, size_t offset) {
+  g_err = std::string("Unexpected ") + what + " at offset '" + std::to_string(offset) + "', State: " + state;   // Display, :27-29
+  return false;
+}
+
+bool ply_parse_strict(const uint8_t *buf, size_t n, tdt_ply &out) {
+  size_t off = 0;
+  auto need = [&](size_t k) { return off + k <= n; };
+  // HeaderSubstate::Ply / Format (:119-134)
+  if (!need(5)) return ply_fail("end of file", "ReadHeader(Ply)", off);
+  if (int64_t e = ply_expect("ply\r\n", buf + off, 5); e >= 0) return ply_fail("character", "ReadHeader(Ply)", static_cast<size_t>(e));
+  off += 5;
+  if (!need(18)) return ply_fail("end of file", "ReadHeader(Format)", off);
+  if (int64_t e = ply_expect("format ascii 1.0\r\n", buf + off, 18); e >= 0) return ply_fail("format", "ReadHeader(Format)", static_cast<size_t>(e));
+  off += 18;
+  for (;;) {   // HeaderSubstate::InferLine (:135-154)
+    if (off >= n) return ply_fail("end of file", "ReadHeader(InferLine)", off);
+    int64_t end = seek_end_word(buf + off, n - off);
+    if (end < 0) return ply_fail("end of file", "ReadHeader(InferLine)", off);
+    const size_t w = static_cast<size_t>(end);
+    if (ply_expect("property", buf + off, w) < 0) {                 // HeaderSubstate::Propery (:177-212)
+      off += 9;
+      if (off >= n) return ply_fail("end of file", "ReadHeader(Propery)", off);
+      int is_pos;
+      if (ply_expect("float", buf + off, n - off) < 0) { off += 6; is_pos = 1; }
+      else if (ply_expect("uchar", buf + off, n - off) < 0) { off += 6; is_pos = 0; }
+      else return ply_fail("type", "ReadHeader(Propery)", off);
+      if (off >= n) return ply_fail("end of file", "ReadHeader(Propery)", off);
+      int id;
+      switch (buf[off]) { case 'x': id = 0; break; case 'y': id = 1; break; case 'z': id = 2; break;
+                          case 'r': id = 3; break; case 'g': id = 4; break; case 'b': id = 5; break;
+                          default: return ply_fail("variable", "ReadHeader(Propery)", off); }
+      out.prop_id.push_back(id); out.prop_is_pos.push_back(is_pos);
+      int64_t eol = seek_end_of_line(buf + off, n - off);
+      if (eol < 0) return ply_fail("end of file", "ReadHeader(Propery)", off);
+      off += static_cast<size_t>(eol) + 2;
+    } else if (ply_expect("comment", buf + off, w) < 0) {           // HeaderSubstate::Comment (:155-160)
+      off += 8;
+      if (off > n) return ply_fail("end of file", "ReadHeader(Comment)", off);
+      int64_t eol = seek_end_of_line(buf + off, n - off);
+      if (eol < 0) return ply_fail("end of file", "ReadHeader(Comment)", off);
+      off += static_cast<size_t>(eol) + 2;
+    } else if (ply_expect("element", buf + off, w) < 0) {           // HeaderSubstate::Element (:161-176)
+      off += 8;
+      if (off > n) return ply_fail("end of file", "ReadHeader(Element)", off);
+      if (int64_t e = ply_expect("vertex", buf + off, n - off); e >= 0) return ply_fail("character", "ReadHeader(Element)", static_cast<size_t>(e));
+      off += 7;
+      if (off > n) return ply_fail("end of file", "ReadHeader(Element)", off);
+      int64_t eol = seek_end_of_line(buf + off, n - off);
+      if (eol < 0) return ply_fail("end of file", "ReadHeader(Element)", off);
+      int64_t v;
+      if (!parse_int(buf + off, static_cast<size_t>(eol), 0, int64_t{1} << 40, false, v)) return ply_fail("vertex count", "ReadHeader(Element)", off);
+      out.header_vertex = v;
+      off += static_cast<size_t>(eol) + 2;
+    } else if (ply_expect("end_header", buf + off, w) < 0) {        // (:149-153)
+      off += 12;
+      break;
+    } else {
+      return ply_fail("header keyword (the reference does not terminate here)", "ReadHeader(InferLine)", off);
+    }
+  }
+  // ReadState::ReadPoint (:243-313)
+  for (;;) {
+    if (off >= n || seek_end_of_line(buf + off, n - off) < 0) break;     // EOF test (:247-250)
+    int32_t pos[3] = {0, 0, 0};
+    uint8_t albedo[3] = {0, 0, 0};
+    uint32_t key = 0;
+    for (size_t k = 0; k < out.prop_id.size(); k++) {
+      if (off > n) return ply_fail("end of file", "ReadPoint", off);
+      int64_t we = seek_end_word(buf + off, n - off);
+      if (we < 0) return ply_fail("end of file", "ReadPoint", off);
+      int64_t v;
+      const int id = out.prop_id[k];
+      if (out.prop_is_pos[k]) {
+        if (!parse_int(buf + off, static_cast<size_t>(we), INT32_MIN, INT32_MAX, true, v)) return ply_fail("FloatParseError", "ReadPoint", off);
+        if (id < 3) { pos[id] = static_cast<int32_t>(v); out.min_point[id] = std::min(out.min_point[id], pos[id]); }
+      } else {
+        if (!parse_int(buf + off, static_cast<size_t>(we), 0, 255, false, v)) return ply_fail("FloatParseError", "ReadPoint", off);
+        if (id >= 3) albedo[id - 3] = static_cast<uint8_t>(v);
+      }
+      key = cantor_pair(albedo[0], albedo[1], albedo[2]);               // after EVERY property (:300)
+      if (!out.albedos.count(key)) out.albedos[key] = {albedo[0], albedo[1], albedo[2]};
+      off += static_cast<size_t>(we) + 1;
+    }
+    out.voxels.insert(out.voxels.end(), {pos[0], pos[1], pos[2], static_cast<int32_t>(key)});
+    off += 1;
+  }
+  return true;
+}
+
+}  // namespace
+
 // ==================================================================== C ABI ===============
 extern "C" {
 
@@ -406,6 +554,107 @@ const void *tdt_scene_blob(const tdt_scene *s, int slot, size_t *bytes) {
 int tdt_scene_counts(const tdt_scene *s, int64_t out[6]) {
   if (!s || !out) { g_err = "null argument"; return 1; }
   for (int i = 0; i < 6; i++) out[i] = s->counts[i];
+  return 0;
+}
+
+int tdt_ply_parse(const void *data, size_t bytes, int strict_crlf, tdt_ply **out) {
+  if (!data || !out) { g_err = "null argument"; return 1; }
+  *out = nullptr;
+  const uint8_t *b = static_cast<const uint8_t *>(data);
+  std::vector<uint8_t> conv;
+  if (!strict_crlf) {   // LF-only file: give every line the CRLF the reference grammar expects
+    bool has_cr = false;
+    for (size_t i = 0; i < bytes; i++) if (b[i] == CR) { has_cr = true; break; }
+    if (!has_cr) {
+      conv.reserve(bytes + bytes / 8);
+      for (size_t i = 0; i < bytes; i++) { if (b[i] == NL) conv.push_back(CR); conv.push_back(b[i]); }
+      b = conv.data(); bytes = conv.size();
+    }
+  }
+  tdt_ply *p = new (std::nothrow) tdt_ply;
+  if (!p) { g_err = "out of memory"; return 1; }
+  try {
+    if (!ply_parse_strict(b, bytes, *p)) { delete p; return 1; }
+  } catch (const std::bad_alloc &) { g_err = "out of memory"; delete p; return 1; }
+  *out = p;
+  return 0;
+}
+
+void tdt_ply_destroy(tdt_ply *p) { delete p; }
+
+int tdt_ply_info(const tdt_ply *p, int64_t *header_vertex, int64_t *n_voxels, int32_t min_point[3], int64_t *n_albedos) {
+  if (!p) { g_err = "null argument"; return 1; }
+  if (header_vertex) *header_vertex = p->header_vertex;
+  if (n_voxels) *n_voxels = static_cast<int64_t>(p->voxels.size() / 4);
+  if (min_point) for (int i = 0; i < 3; i++) min_point[i] = p->min_point[i];
+  if (n_albedos) *n_albedos = static_cast<int64_t>(p->albedos.size());
+  return 0;
+}
+
+const int32_t *tdt_ply_voxels(const tdt_ply *p) { return p ? p->voxels.data() : nullptr; }
+
+int64_t tdt_ply_albedos(const tdt_ply *p, uint32_t *keys, uint8_t *rgb, int64_t capacity) {
+  if (!p) return 0;
+  int64_t i = 0;
+  for (const auto &kv : p->albedos) {
+    if (i >= capacity) break;
+    if (keys) keys[i] = kv.first;
+    if (rgb) { rgb[3 * i] = kv.second[0]; rgb[3 * i + 1] = kv.second[1]; rgb[3 * i + 2] = kv.second[2]; }
+    i++;
+  }
+  return i;
+}
+
+int tdt_scene_from_ply(const tdt_ply *p, int max_iter, int z_up, tdt_scene **out) {
+  if (!p || !out) { g_err = "null argument"; return 1; }
+  *out = nullptr;
+  const size_t nv = p->voxels.size() / 4;
+  if (nv == 0) { g_err = "the PLY holds no voxels"; return 1; }
+  int32_t mx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+  for (size_t i = 0; i < nv; i++) for (int a = 0; a < 3; a++) mx[a] = std::max(mx[a], p->voxels[4 * i + a]);
+  int64_t ext[3];
+  for (int a = 0; a < 3; a++) ext[a] = static_cast<int64_t>(mx[a]) - p->min_point[a] + 1;
+  const int64_t emax = std::max(ext[0], std::max(ext[1], ext[2]));
+  int depth = 1;
+  while ((int64_t{1} << depth) < emax) depth++;
+  if (depth > 9) { g_err = "model larger than 512 voxels on an edge"; return 1; }
+  tdt_scene *s = new (std::nothrow) tdt_scene;
+  if (!s) { g_err = "out of memory"; return 1; }
+  try {
+    // one Lambertian material per colour that a voxel really ends up with (not the polluted palette)
+    std::map<uint32_t, uint32_t> mat_of_key;
+    for (size_t i = 0; i < nv; i++) mat_of_key.emplace(static_cast<uint32_t>(p->voxels[4 * i + 3]), 0u);
+    if (mat_of_key.size() > 254) { g_err = "more than 254 distinct colours"; delete s; return 1; }
+    uint32_t m = 0;
+    for (auto &kv : mat_of_key) {
+      kv.second = m;
+      const auto &rgb = p->albedos.at(kv.first);
+      s->materials.insert(s->materials.end(), {LAMBERTIAN, 0u, m});
+      for (int c = 0; c < 3; c++) s->albedos.push_back(static_cast<float>(rgb[c]) / 255.0f);
+      m++;
+    }
+    s->metal = {0.1f, 0.3f, 0.4f, 0.8f};     // the reference's tables (main.rs:418-441); unused by Lambertian voxels
+    s->dielectric = {1.2f};
+    Grid g(depth);
+    const int N = g.n;
+    // file axes -> octree axes; centred in x, on the floor, at the far (z = 0) side
+    const int ax = 0, ay = z_up ? 2 : 1, az = z_up ? 1 : 2;
+    const int ox = static_cast<int>((N - ext[ax]) / 2), oy = 0, oz = 0;
+    for (size_t i = 0; i < nv; i++) {
+      const int x = p->voxels[4 * i + ax] - p->min_point[ax] + ox;
+      const int y = p->voxels[4 * i + ay] - p->min_point[ay] + oy;
+      const int z = p->voxels[4 * i + az] - p->min_point[az] + oz;
+      g.set(x, y, z, static_cast<uint8_t>(1 + mat_of_key[static_cast<uint32_t>(p->voxels[4 * i + 3])]));
+    }
+    int cell_count = 1 << 10;
+    for (;;) {
+      if (build_octree(g, *s, cell_count)) break;
+      if (cell_count >= (1 << 22)) { delete s; return 1; }
+      cell_count <<= 1;
+    }
+    set_octree_uniforms(*s, -0.5f, -0.5f, -1.0f, 1.0f, depth, max_iter, cell_count);
+  } catch (const std::bad_alloc &) { g_err = "out of memory"; delete s; return 1; }
+  *out = s;
   return 0;
 }
 

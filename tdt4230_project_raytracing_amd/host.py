@@ -171,3 +171,55 @@ def camera_reference_pose(width, height, spp, max_bounce):
     u = CameraUniforms()
     _check(lib().tdt_camera_reference_pose(width, height, spp, max_bounce, ctypes.byref(u)))
     return u
+
+
+# ---------------------------------------------------------------- scene ingest ---
+def cantor_pair(r, g, b):
+    """ply_point_loader.rs:228-241 (f64 arithmetic, saturating `as u32`)."""
+    fd = 0.5 * (r + g) * (r + g + 1.0) + g
+    h = 0.5 * (fd + b) * (fd + b + 1.0) + b
+    return 0xFFFFFFFF if h >= 4294967295.0 else int(h)
+
+
+class Ply:
+    """PlyFileContent of ply_point_loader::from_resources (ply_point_loader.rs:84-93) for a byte buffer."""
+
+    def __init__(self, data, strict_crlf=True):
+        L = lib()
+        L.tdt_ply_parse.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        L.tdt_ply_destroy.argtypes = [ctypes.c_void_p]
+        L.tdt_ply_destroy.restype = None
+        L.tdt_ply_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+                                   ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)]
+        L.tdt_ply_voxels.argtypes = [ctypes.c_void_p]
+        L.tdt_ply_voxels.restype = ctypes.POINTER(ctypes.c_int32)
+        L.tdt_ply_albedos.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+        L.tdt_ply_albedos.restype = ctypes.c_int64
+        L.tdt_scene_from_ply.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        h = ctypes.c_void_p()
+        _check(L.tdt_ply_parse(bytes(data), len(data), 1 if strict_crlf else 0, ctypes.byref(h)))
+        self._h = h
+        hv, nv, na = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        mp = (ctypes.c_int32 * 3)()
+        _check(L.tdt_ply_info(h, ctypes.byref(hv), ctypes.byref(nv), mp, ctypes.byref(na)))
+        self.header_vertex, self.min_point = hv.value, list(mp)
+        n = nv.value
+        v = np.ctypeslib.as_array(L.tdt_ply_voxels(h), shape=(n, 4)).copy() if n else np.zeros((0, 4), np.int32)
+        self.positions = v[:, :3]
+        self.albedo_keys = v[:, 3].view(np.uint32) if n else np.zeros(0, np.uint32)
+        keys = np.zeros(na.value, np.uint32)
+        rgb = np.zeros((na.value, 3), np.uint8)
+        L.tdt_ply_albedos(h, keys.ctypes.data, rgb.ctypes.data, na.value)
+        self.albedos = {int(k): tuple(int(c) for c in col) for k, col in zip(keys, rgb)}
+
+    def to_scene(self, max_iter=256, z_up=True):
+        h = ctypes.c_void_p()
+        _check(lib().tdt_scene_from_ply(self._h, max_iter, 1 if z_up else 0, ctypes.byref(h)))
+        return Scene._from_handle(h, "ply")
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().tdt_ply_destroy(self._h)
+        except Exception:
+            pass

@@ -14,6 +14,14 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+def _scene(z, spec):
+    if spec[0] == "config":
+        return host.Scene.config(spec[1])
+    if spec[0] == "ply":          # built from the reference's model file when the fixture was made: payloads stored
+        return host.Scene({int(k[5:]): z[k] for k in z.files if k.startswith("blob_")}, name=spec[1])
+    return host.Scene.generate(*spec[1:])
+
+
 def _camera(meta):
     """main.rs:165-168's camera for the fixture's size, optionally moved to the fixture's origin."""
     if meta.get("origin") is None:
@@ -34,7 +42,7 @@ def test_gpu_bit_exact_vs_reference_render(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     meta = json.loads(str(z["meta"]))
     spec = meta["scene"]
-    scene = host.Scene.config(spec[1]) if spec[0] == "config" else host.Scene.generate(*spec[1:])
+    scene = _scene(z, spec)
     cam = _camera(meta)
     r = rt.Renderer(scene, cam)
     try:
