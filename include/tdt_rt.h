@@ -46,7 +46,8 @@ enum {
 /* kinds for tdt_compute_create (the two compute programs the reference links) */
 enum {
   TDT_PROGRAM_RAYTRACER = 0,      /* assets/shaders/raytracer.comp */
-  TDT_PROGRAM_OCTREE_UPDATE = 1   /* assets/shaders/octree_update.comp — not built: TDT_ERR_INVALID_ENUM */
+  TDT_PROGRAM_OCTREE_UPDATE = 1   /* assets/shaders/octree_update.comp (next row SURVEY §8f-2): one voxel edit per
+                                     invocation; reads slots 0,5,6,7 + the atomic counter, group size {1,1,1} */
 };
 /* targets for tdt_bind_buffer_base (values are the GL enums the reference passes) */
 enum {
@@ -60,7 +61,7 @@ enum {
   TDT_SLOT_ALBEDOS = 2,      /* {float x,y,z}[]                                :203-210 */
   TDT_SLOT_METAL = 3,        /* {float fuzz}[]                                 :214-219 */
   TDT_SLOT_DIELECTRIC = 4,   /* {float ir}[]                                   :222-227 */
-  TDT_SLOT_DELTA = 5,        /* octree_update.comp only; accepted, ignored               */
+  TDT_SLOT_DELTA = 5,        /* DeltaNode{vec3 pos; float type; float value}[] stride 32   octree_update.comp:41-48 */
   TDT_SLOT_OCTREE_FLOATS = 6,/* {vec4 min_point; float scale, inv_scale, inv_cell_count} :150-158 */
   TDT_SLOT_OCTREE_INTS = 7   /* {int max_depth, max_iter, cell_count}          :159-166 */
 };
@@ -100,8 +101,10 @@ int tdt_buffer_create(tdt_ctx *ctx, const void *data, size_t bytes, tdt_buffer *
 void tdt_buffer_destroy(tdt_buffer *b);
 /* gl::BindBufferBase(target, slot, id) as called by main.rs:352-448 and octree.rs:67-144 */
 int tdt_bind_buffer_base(tdt_ctx *ctx, int target, unsigned slot, tdt_buffer *b);
-/* gl::BufferSubData (octree.rs:174); only meaningful for the edit path (next row §8f-2) */
+/* gl::BufferSubData (octree.rs:174): how Octree::update_vbo hands the delta nodes to the edit program */
 int tdt_buffer_sub_data(tdt_buffer *b, size_t offset, size_t bytes, const void *data);
+/* NEW (the reference never reads a buffer back): finishes the stream and copies bytes to dst */
+int tdt_buffer_read(tdt_buffer *b, size_t offset, size_t bytes, void *dst);
 
 /* ---- image ------------------------------------------------------------------------------ */
 /* Texture::new_2d(TEXTURE0, 0, RGBA32F, RGBA, w, h) (texture.rs:47-75, camera.rs:158-165):
@@ -123,8 +126,8 @@ int tdt_image_read(tdt_image *img, float *dst);
 
 /* ---- dispatch --------------------------------------------------------------------------- */
 /* ComputeShader::dispatch_compute(width, height, depth) (compute_shader.rs:28-38; called with
- * (W+1, H+1, 1) at main.rs:579): work-group counts are max(dim / 32, 1) by integer floor
- * division, the shader has no bounds check, image stores outside the image are dropped;
+ * (W+1, H+1, 1) at main.rs:579, and by Octree::update_vbo octree.rs:179,181 for the edit program):
+ * work-group counts are max(dim / group_size, 1) by integer floor division; for the raytracer the shader has no bounds check, image stores outside the image are dropped;
  * followed by the image-access barrier (= stream order here).  Asynchronous. */
 int tdt_dispatch_compute(tdt_compute *c, int width, int height, int depth);
 

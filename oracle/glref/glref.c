@@ -205,6 +205,20 @@ int glref_ssbo(unsigned slot, const void *data, size_t bytes) {
   return (int)p_glGetError();
 }
 
+/* VertexBufferObject::new(.., gl::ATOMIC_COUNTER_BUFFER, ..) + gl::BindBufferBase(ATOMIC_COUNTER_BUFFER, slot)
+ * (octree.rs:105-117); read it back with glref_ssbo_read(index) like any other buffer */
+int glref_atomic_counter(unsigned slot, const void *data, size_t bytes) {
+  if (g_nbufs >= MAX_BUFS) { snprintf(g_err, sizeof g_err, "too many buffers"); return -1; }
+  GLuint b = 0;
+  p_glGenBuffers(1, &b);
+  p_glBindBuffer(GL_ATOMIC_COUNTER_BUFFER, b);
+  p_glBufferData(GL_ATOMIC_COUNTER_BUFFER, (GLsizeiptr)bytes, data, GL_DYNAMIC_COPY);
+  p_glBindBufferBase(GL_ATOMIC_COUNTER_BUFFER, slot, b);
+  g_bufs[g_nbufs++] = b;
+  return (int)p_glGetError();
+}
+int glref_buffer_count(void) { return g_nbufs; }
+
 /* read back an SSBO bound earlier (used by test-only micro shaders) */
 int glref_ssbo_read(int index, void *dst, size_t bytes) {
   if (index < 0 || index >= g_nbufs) return -1;
@@ -276,7 +290,7 @@ double glref_dispatch_compute(int width, int height, int depth) {
   clock_gettime(CLOCK_MONOTONIC, &t0);
   p_glUseProgram(g_prog);
   p_glDispatchCompute(gx, gy, gz);
-  p_glMemoryBarrier(GL_SHADER_IMAGE_ACCESS_BARRIER_BIT | GL_SHADER_STORAGE_BARRIER_BIT);
+  p_glMemoryBarrier(GL_SHADER_IMAGE_ACCESS_BARRIER_BIT | GL_SHADER_STORAGE_BARRIER_BIT | GL_ATOMIC_COUNTER_BARRIER_BIT);
   p_glUseProgram(0);
   p_glFinish();
   clock_gettime(CLOCK_MONOTONIC, &t1);

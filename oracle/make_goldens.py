@@ -117,6 +117,40 @@ def math_table():
     print("math_table:", tab.shape)
 
 
+# voxel edits: name -> (scene spec, extra zeroed cells, counter before, deltas [pos xyz, type, value], dispatch)
+EDITS = {
+    "edit_demo_click": (("config", 0), 0, 19, [[0.3, 0.6, 0.2, 2.0, 5.0]], (0, 1, 0)),            # main.rs:561-568 -> update_vbo(delta, 5)
+    "edit_demo_three": (("config", 0), 0, 19, [[0.51, 0.45, 0.31, 2.0, 3.0], [0.52, 0.45, 0.31, 2.0, 4.0], [0.9, 0.1, 0.8, 0.0, 0.0]], (0, 3, 0)),
+    "edit_config2_two": (("config", 2), 64, 4209, [[0.5, 0.42, 0.62, 2.0, 13.0], [0.47, 0.40, 0.60, 2.0, 18.0]], (0, 2, 0)),
+    "edit_demo_out_of_room": (("config", 0), -(100144 - 21 * 16), 19, [[0.3, 0.6, 0.2, 2.0, 5.0]], (0, 1, 0)),   # cells buffer cut to 21 cells
+}
+
+
+def edits():
+    """octree_update.comp run by the reference on llvmpipe: cells / counter after the edit, and a render of the edited tree."""
+    gl = oracle_py.GLRef.get()
+    for name, (spec, pad, counter, deltas, dispatch) in EDITS.items():
+        scene = make_scene(spec)
+        if pad > 0:
+            scene.blobs[0] = np.concatenate([scene.blobs[0], np.zeros(16 * pad, np.uint32)])
+        elif pad < 0:
+            scene.blobs[0] = scene.blobs[0][:pad].copy()
+        delta = np.zeros((len(deltas), 8), np.float32)          # DeltaNode stride 32 bytes
+        delta[:, :5] = np.array(deltas, np.float32)
+        before = scene.blobs[0].copy()
+        cells, cnt = oracle_py.glref_octree_update(scene, delta, counter, dispatch)
+        changed = np.nonzero(cells != before)[0].astype(np.uint32)
+        scene.blobs[0] = cells
+        cam = host.camera_reference_pose(128, 96, 2, 6)
+        img = gl.render(scene, cam)
+        meta = {"scene": list(spec), "pad": pad, "counter_before": counter, "dispatch": list(dispatch),
+                "counter_after": cnt, "scene_sha256_before": hashlib.sha256(before.tobytes()).hexdigest()}
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), delta=delta, changed_index=changed, changed_value=cells[changed],
+                            image=img, meta=json.dumps(meta))
+        print(f"{name}: {changed.size} dwords changed, counter {counter} -> {cnt}")
+
+
 if __name__ == "__main__":
     main()
     math_table()
+    edits()

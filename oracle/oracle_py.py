@@ -228,3 +228,49 @@ def glref_math_table(xs):
     g._prog = None
     g.L.glref_free_buffers()
     return out.reshape(n, 8)[:xs.size]
+
+
+# ---- next row §8f-2: assets/shaders/octree_update.comp ---------------------------------------------
+UPDATE_SHADER = os.path.join(REF_DIR, "assets", "shaders", "octree_update.comp")
+
+
+def oracle_octree_update(oracle, scene, delta, counter, dispatch):
+    """Oracle restatement of the edit kernel: returns (cells_after, counter_after)."""
+    L = oracle.L
+    L.oracle_octree_update.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                       ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                       ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    cells = np.ascontiguousarray(scene.blobs[0]).copy()
+    d = np.ascontiguousarray(delta, np.float32)
+    of, oi = np.ascontiguousarray(scene.blobs[6]), np.ascontiguousarray(scene.blobs[7])
+    c = ctypes.c_uint32(counter)
+    L.oracle_octree_update(cells.ctypes.data, cells.nbytes, d.ctypes.data, d.nbytes, of.ctypes.data, of.nbytes,
+                           oi.ctypes.data, oi.nbytes, ctypes.byref(c), *dispatch)
+    return cells, int(c.value)
+
+
+def glref_octree_update(scene, delta, counter, dispatch):
+    """The reference's own octree_update.comp on llvmpipe: returns (cells_after, counter_after)."""
+    g = GLRef.get()
+    L = g.L
+    L.glref_atomic_counter.argtypes = [ctypes.c_uint, ctypes.c_void_p, ctypes.c_size_t]
+    g.program(UPDATE_SHADER)
+    g._prog = None
+    L.glref_free_buffers()
+    idx = {}
+    for slot in (0, 6, 7):
+        a = np.ascontiguousarray(scene.blobs[slot])
+        idx[slot] = L.glref_buffer_count()
+        assert L.glref_ssbo(slot, a.ctypes.data, a.nbytes) == 0
+    d = np.ascontiguousarray(delta, np.float32)
+    assert L.glref_ssbo(5, d.ctypes.data, d.nbytes) == 0
+    c = np.array([counter], np.uint32)
+    ic = L.glref_buffer_count()
+    assert L.glref_atomic_counter(0, c.ctypes.data, 4) == 0
+    assert L.glref_dispatch_compute(*dispatch) >= 0
+    cells = np.zeros_like(np.ascontiguousarray(scene.blobs[0]))
+    assert L.glref_ssbo_read(idx[0], cells.ctypes.data, cells.nbytes) == 0
+    cnt = np.zeros(1, np.uint32)
+    assert L.glref_ssbo_read(ic, cnt.ctypes.data, 4) == 0
+    L.glref_free_buffers()
+    return cells, int(cnt[0])

@@ -572,3 +572,60 @@ int oracle_resolve(const oracle_camera *cam, int dispatch_w, int dispatch_h, int
     }
   return 0;
 }
+
+/* ---------------------------------------------------------------- octree_update.comp ---- */
+/* uc:N = assets/shaders/octree_update.comp line N.  float -> uint as llvmpipe's f2u32 (values used by
+ * the reference host are small non-negative integers, main.rs:566-567). */
+static inline uint32_t f2u(float f) {
+  if (!(f > -1.0f)) return 0u;
+  if (f >= 4294967296.0f) return 0xFFFFFFFFu;
+  return (uint32_t)f;
+}
+static inline void st_u32(void *buf, size_t bytes, uint32_t byte_off, uint32_t v) {
+  if ((size_t)(byte_off >> 2) >= (bytes >> 2)) return;            /* robust access: dropped */
+  memcpy((char *)buf + (byte_off & ~3u), &v, 4);
+}
+
+static void update_invocation(void *cells, size_t cb, const void *delta, size_t db, float inv_cell_count,
+                              int32_t max_depth, int32_t cell_count, uint32_t *counter, uint32_t delta_index) {
+  const uint32_t dof = delta_index << 5;                                   /* DeltaNode stride 32 */
+  float cx = ld_f32(delta, db, dof), cy = ld_f32(delta, db, dof + 4), cz = ld_f32(delta, db, dof + 8);
+  const float d_type = ld_f32(delta, db, dof + 12), d_value = ld_f32(delta, db, dof + 16);
+  const float two_cc = (float)(int32_t)((uint32_t)cell_count << 1);
+  uint32_t node_value = 0, index = 0;                                      /* index: undefined when the loop is empty */
+  for (float i = 0.0f; i < (float)(max_depth - 1); i = i + 1.0f) {        /* treeLookupLeaf uc:57-80 */
+    float fx = f_fract(cx), fy = f_fract(cy), fz = f_fract(cz);
+    float rx = rintf((((float)node_value + fx) * inv_cell_count) * two_cc + -0.5f);
+    float ry = rintf(fy * 2.0f + -0.5f), rz = rintf(fz * 2.0f + -0.5f);
+    index = ((((uint32_t)f2i(rx) << 1) + (uint32_t)f2i(ry)) << 1) + (uint32_t)f2i(rz);
+    const uint32_t off = index << 3;
+    /* atomicCompSwap(type, EMPTY, PARENT) == EMPTY -> allocate a cell (uc:72-74) */
+    {   /* an out-of-range atomic returns 0 and writes nothing (llvmpipe), so it still takes a counter value */
+      const uint32_t old = ld_u32(cells, cb, off + 4);
+      if (old == 0u) {
+        st_u32(cells, cb, off + 4, 1u);
+        st_u32(cells, cb, off, (*counter)++);
+      }
+    }
+    node_value = ld_u32(cells, cb, off);                                   /* node = indirect_cells[index] uc:76 */
+    cx = cx * 2.0f; cy = cy * 2.0f; cz = cz * 2.0f;
+  }
+  st_u32(cells, cb, index << 3, f2u(d_value));                             /* uc:101 */
+  st_u32(cells, cb, (index << 3) + 4, f2u(d_type));
+}
+
+int oracle_octree_update(void *cells, size_t cells_bytes, const void *delta, size_t delta_bytes,
+                         const void *octree_floats, size_t octree_floats_bytes,
+                         const void *octree_ints, size_t octree_ints_bytes, uint32_t *counter,
+                         int dispatch_w, int dispatch_h, int dispatch_d) {
+  const float inv_cell_count = ld_f32(octree_floats, octree_floats_bytes, 24);
+  const int32_t max_depth = (int32_t)ld_u32(octree_ints, octree_ints_bytes, 0);
+  const int32_t cell_count = (int32_t)ld_u32(octree_ints, octree_ints_bytes, 8);
+  const int gx = dispatch_w < 1 ? 1 : dispatch_w, gy = dispatch_h < 1 ? 1 : dispatch_h, gz = dispatch_d < 1 ? 1 : dispatch_d;
+  for (int z = 0; z < gz; z++)
+    for (int y = 0; y < gy; y++)
+      for (int x = 0; x < gx; x++)
+        update_invocation(cells, cells_bytes, delta, delta_bytes, inv_cell_count, max_depth, cell_count, counter,
+                          (uint32_t)x + (uint32_t)y + (uint32_t)z);            /* uc:99 */
+  return 0;
+}

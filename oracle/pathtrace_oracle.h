@@ -67,6 +67,18 @@ int oracle_accumulate(const oracle_scene *scene, const oracle_camera *cam,
 int oracle_resolve(const oracle_camera *cam, int dispatch_w, int dispatch_h, int row_begin, int row_end,
                    int total_spp, const float *accum, float *image);
 
+/* ---- next row §8f-2: the voxel edit kernel, assets/shaders/octree_update.comp (as compiled) ----
+ * Executes the dispatch ComputeShader::dispatch_compute(dispatch_w, dispatch_h, dispatch_d) of the
+ * update program (work-group size 1: groups = max(dim, 1)), one invocation after the other in
+ * x-fastest order (the reference's own outcome is racy when several invocations collide;
+ * octree_update.comp:70-71).  `cells` is modified in place; `*counter` is the atomic counter
+ * (binding 0).  delta = DeltaNode[] with the std430 layout the shader declares: pos at 0, type at
+ * 12, value at 16, stride 32 (octree_update.comp:41-48).  Returns 0. */
+int oracle_octree_update(void *cells, size_t cells_bytes, const void *delta, size_t delta_bytes,
+                         const void *octree_floats, size_t octree_floats_bytes,
+                         const void *octree_ints, size_t octree_ints_bytes, uint32_t *counter,
+                         int dispatch_w, int dispatch_h, int dispatch_d);
+
 /* llvmpipe's sin/cos/pow (gallivm polynomial forms) exposed for unit tests */
 float oracle_sin(float a);
 float oracle_cos(float a);

@@ -365,6 +365,48 @@ __global__ __launch_bounds__(256) void selftest_kernel(int which, unsigned long 
   if ((threadIdx.x & 63) == 0 && bad) atomicAdd(mismatches, bad);
 }
 
+// ---- next row §8f-2: assets/shaders/octree_update.comp (uc:N = its line N) ------------------------
+// One voxel edit per invocation: walk max_depth-1 levels with treeLookup's index arithmetic, turning
+// EMPTY nodes on the way into PARENTs of freshly counted cells (atomicCompSwap + atomic counter,
+// uc:72-74), then overwrite the last node visited with the delta (uc:101).  The reference's
+// invocations race when their paths collide (its own comment, uc:70-71); the only implementation of
+// it that can be run (llvmpipe) executes work-groups one after the other, and that order is what
+// this kernel reproduces: ONE lane walks the dispatch in x-fastest order, so results are
+// deterministic and equal to the oracle's.  Edits are a handful of nodes; speed is irrelevant.
+__global__ __launch_bounds__(64) void octree_update_kernel(uint32_t *cells, uint32_t cells_dwords, const uint32_t *delta,
+                                                          uint32_t delta_dwords, float inv_cell_count, int max_depth,
+                                                          int cell_count, uint32_t *counter, int gx, int gy, int gz) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float two_cc = (float)(int32_t)((uint32_t)cell_count << 1);
+  for (int z = 0; z < gz; z++) for (int y = 0; y < gy; y++) for (int x = 0; x < gx; x++) {
+    const uint32_t dof = ((uint32_t)x + (uint32_t)y + (uint32_t)z) << 5;      // delta_index uc:99, DeltaNode stride 32
+    float cx = __uint_as_float(ld_dw(delta, delta_dwords, dof)), cy = __uint_as_float(ld_dw(delta, delta_dwords, dof + 4)),
+          cz = __uint_as_float(ld_dw(delta, delta_dwords, dof + 8));
+    const float d_type = __uint_as_float(ld_dw(delta, delta_dwords, dof + 12)), d_value = __uint_as_float(ld_dw(delta, delta_dwords, dof + 16));
+    uint32_t node_value = 0, index = 0;
+    for (float i = 0.0f; i < (float)(max_depth - 1); i = i + 1.0f) {          // treeLookupLeaf uc:57-80
+      const float fx = f_fract(cx), fy = f_fract(cy), fz = f_fract(cz);
+      const float rx = __builtin_rintf((((float)node_value + fx) * inv_cell_count) * two_cc + -0.5f);
+      const float ry = __builtin_rintf(fy * 2.0f + -0.5f), rz = __builtin_rintf(fz * 2.0f + -0.5f);
+      index = ((((uint32_t)f2i(rx) << 1) + (uint32_t)f2i(ry)) << 1) + (uint32_t)f2i(rz);
+      const uint32_t dw = (index << 3) >> 2;
+      const uint32_t old = (dw + 1u < cells_dwords) ? cells[dw + 1u] : 0u;      // an out-of-range atomic returns 0, writes nothing
+      if (old == 0u) {
+        const uint32_t fresh = (*counter)++;
+        if (dw + 1u < cells_dwords) cells[dw + 1u] = 1u;
+        if (dw < cells_dwords) cells[dw] = fresh;
+      }
+      node_value = (dw < cells_dwords) ? cells[dw] : 0u;                        // node = indirect_cells[index] uc:76
+      cx = cx * 2.0f; cy = cy * 2.0f; cz = cz * 2.0f;
+    }
+    const uint32_t dw = (index << 3) >> 2;
+    const uint32_t uv = !(d_value > -1.0f) ? 0u : (d_value >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)d_value);
+    const uint32_t ut = !(d_type > -1.0f) ? 0u : (d_type >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)d_type);
+    if (dw < cells_dwords) cells[dw] = uv;                                      // uc:101
+    if (dw + 1u < cells_dwords) cells[dw + 1u] = ut;
+  }
+}
+
 // De-interleave gathered per-rank tile buffers ([rank][k][32][32] RGBA) into a W x H image.
 __global__ __launch_bounds__(256) void assemble_kernel(const float4 *__restrict__ tiles, float4 *__restrict__ image,
                                                        int image_width, int cover_w, int cover_h, int tiles_x,
@@ -681,8 +723,8 @@ const char *tdt_strerror(int code) {
 int tdt_compute_create(tdt_ctx *ctx, int kind, tdt_compute **out) {
   if (!ctx || !out) return fail(ctx, TDT_ERR_INVALID_VALUE, "null argument");
   *out = nullptr;
-  if (kind != TDT_PROGRAM_RAYTRACER)
-    return fail(ctx, TDT_ERR_INVALID_ENUM, "only TDT_PROGRAM_RAYTRACER is built (octree_update.comp is a next row, SURVEY §8f-2)");
+  if (kind != TDT_PROGRAM_RAYTRACER && kind != TDT_PROGRAM_OCTREE_UPDATE)
+    return fail(ctx, TDT_ERR_INVALID_ENUM, "unknown program kind");
   tdt_compute *c = new (std::nothrow) tdt_compute();
   if (!c) return fail(ctx, TDT_ERR_HIP, "out of host memory");
   std::memset(c, 0, sizeof *c);
@@ -700,6 +742,7 @@ void tdt_compute_destroy(tdt_compute *c) {
 
 int tdt_compute_group_size(const tdt_compute *c, int out[3]) {
   if (!c || !out) return TDT_ERR_INVALID_VALUE;
+  if (c->kind == TDT_PROGRAM_OCTREE_UPDATE) { out[0] = 1; out[1] = 1; out[2] = 1; return TDT_OK; }   // octree_update.comp:3
   out[0] = 32; out[1] = 32; out[2] = 1;   // layout(local_size_x = 32, local_size_y = 32) raytracer.comp:3
   return TDT_OK;
 }
@@ -711,7 +754,7 @@ static int not_found(tdt_compute *c, const char *name, const char *type) {
 
 int tdt_set_i32(tdt_compute *c, const char *name, int32_t v) {
   if (!c) return TDT_ERR_INVALID_VALUE;
-  if (name) {
+  if (name && c->kind == TDT_PROGRAM_RAYTRACER) {
     if (!std::strcmp(name, "camera.image_width")) { c->image_width = v; return TDT_OK; }
     if (!std::strcmp(name, "camera.image_height")) { c->image_height = v; return TDT_OK; }
     if (!std::strcmp(name, "camera.samples_per_pixel")) { c->samples_per_pixel = v; return TDT_OK; }
@@ -728,7 +771,7 @@ int tdt_set_f32(tdt_compute *c, const char *name, float) {
 int tdt_set_vec3f(tdt_compute *c, const char *name, float x, float y, float z) {
   if (!c) return TDT_ERR_INVALID_VALUE;
   float *dst = nullptr;
-  if (name) {
+  if (name && c->kind == TDT_PROGRAM_RAYTRACER) {
     if (!std::strcmp(name, "camera.horizontal")) dst = c->horizontal;
     else if (!std::strcmp(name, "camera.vertical")) dst = c->vertical;
     else if (!std::strcmp(name, "camera.lower_left_corner")) dst = c->lower_left_corner;
@@ -794,6 +837,18 @@ int tdt_bind_buffer_base(tdt_ctx *ctx, int target, unsigned slot, tdt_buffer *b)
     return TDT_OK;
   }
   return fail(ctx, TDT_ERR_INVALID_ENUM, "unknown buffer target");
+}
+
+int tdt_buffer_read(tdt_buffer *b, size_t offset, size_t bytes, void *dst) {
+  if (!b) return TDT_ERR_INVALID_VALUE;
+  tdt_ctx *ctx = b->ctx;
+  if (offset > b->bytes || bytes > b->bytes - offset) return fail(ctx, TDT_ERR_INVALID_VALUE, "read range outside the buffer");
+  if (!bytes) return TDT_OK;
+  if (!dst) return fail(ctx, TDT_ERR_INVALID_VALUE, "null destination");
+  TDT_HIP(ctx, hipSetDevice(ctx->device));
+  TDT_HIP(ctx, hipMemcpyAsync(dst, (const char *)b->dev + offset, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  TDT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return TDT_OK;
 }
 
 int tdt_buffer_sub_data(tdt_buffer *b, size_t offset, size_t bytes, const void *data) {
@@ -875,8 +930,32 @@ int tdt_image_read(tdt_image *img, float *dst) {
   return TDT_OK;
 }
 
+static int launch_update(tdt_compute *c, int width, int height, int depth) {
+  tdt_ctx *ctx = c->ctx;
+  static const int required[] = {TDT_SLOT_CELLS, TDT_SLOT_DELTA, TDT_SLOT_OCTREE_FLOATS, TDT_SLOT_OCTREE_INTS};
+  for (int s : required)
+    if (!ctx->ssbo[s]) return fail(ctx, TDT_ERR_INCOMPLETE, "no buffer bound to shader-storage slot " + std::to_string(s));
+  if (!ctx->atomic0 || ctx->atomic0->bytes < 4) return fail(ctx, TDT_ERR_INCOMPLETE, "no atomic-counter buffer bound to slot 0");
+  if (ctx->ssbo[TDT_SLOT_OCTREE_FLOATS]->bytes < 28 || ctx->ssbo[TDT_SLOT_OCTREE_INTS]->bytes < 12)
+    return fail(ctx, TDT_ERR_INVALID_VALUE, "octree uniform buffers are too small (need 28 / 12 bytes)");
+  float of[7]; int32_t oi[3];
+  std::memcpy(of, ctx->ssbo[TDT_SLOT_OCTREE_FLOATS]->shadow, sizeof of);
+  std::memcpy(oi, ctx->ssbo[TDT_SLOT_OCTREE_INTS]->shadow, sizeof oi);
+  // ComputeShader::dispatch_compute with group_size {1,1,1}: groups = max(dim / 1, 1) (compute_shader.rs:30-32)
+  const int gx = width < 1 ? 1 : width, gy = height < 1 ? 1 : height, gz = depth < 1 ? 1 : depth;
+  tdt_buffer *cells = ctx->ssbo[TDT_SLOT_CELLS], *delta = ctx->ssbo[TDT_SLOT_DELTA];
+  auto dwords = [](const tdt_buffer *b) { size_t d = b->bytes >> 2; return (uint32_t)(d > 0xFFFFFFFFull ? 0xFFFFFFFFull : d); };
+  TDT_HIP(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(tdt::octree_update_kernel, dim3(1), dim3(64), 0, ctx->stream, (uint32_t *)cells->dev, dwords(cells),
+                     (const uint32_t *)delta->dev, dwords(delta), of[6], oi[0], oi[2], (uint32_t *)ctx->atomic0->dev, gx, gy, gz);
+  TDT_HIP(ctx, hipGetLastError());
+  cells->version += 0x100000000ull;      // the trace's LDS-table image / scan of this buffer are stale now
+  return TDT_OK;
+}
+
 int tdt_dispatch_compute(tdt_compute *c, int width, int height, int depth) {
   if (!c) return TDT_ERR_INVALID_VALUE;
+  if (c->kind == TDT_PROGRAM_OCTREE_UPDATE) return launch_update(c, width, height, depth);
   return launch(c, width, height, depth, 0, 0, c->samples_per_pixel, nullptr, c->samples_per_pixel, nullptr);
 }
 
@@ -889,6 +968,7 @@ int tdt_set_partition(tdt_compute *c, int rank, int world) {
 
 int tdt_dispatch_accumulate(tdt_compute *c, int width, int height, int depth, int spp_begin, int spp_count, void *carry) {
   if (!c) return TDT_ERR_INVALID_VALUE;
+  if (c->kind != TDT_PROGRAM_RAYTRACER) return fail(c->ctx, TDT_ERR_INVALID_OPERATION, "not the raytracer program");
   if (spp_begin < 0 || spp_count < 0) return fail(c->ctx, TDT_ERR_INVALID_VALUE, "negative sample range");
   if (carry && ((uintptr_t)carry & 15) != 0) return fail(c->ctx, TDT_ERR_INVALID_VALUE, "carry memory must be 16-byte aligned");
   return launch(c, width, height, depth, 1, spp_begin, spp_count, carry, 0, nullptr);
@@ -896,6 +976,7 @@ int tdt_dispatch_accumulate(tdt_compute *c, int width, int height, int depth, in
 
 int tdt_dispatch_resolve(tdt_compute *c, int width, int height, int depth, int total_spp) {
   if (!c) return TDT_ERR_INVALID_VALUE;
+  if (c->kind != TDT_PROGRAM_RAYTRACER) return fail(c->ctx, TDT_ERR_INVALID_OPERATION, "not the raytracer program");
   return launch(c, width, height, depth, 2, 0, 0, nullptr, total_spp, nullptr);
 }
 
@@ -917,6 +998,7 @@ int tdt_owned_tiles(const tdt_compute *c, int width, int height, int depth, int 
 
 int tdt_dispatch_counted(tdt_compute *c, int width, int height, int depth, uint64_t counts[8]) {
   if (!c || !counts) return TDT_ERR_INVALID_VALUE;
+  if (c->kind != TDT_PROGRAM_RAYTRACER) return fail(c->ctx, TDT_ERR_INVALID_OPERATION, "not the raytracer program");
   static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "");
   return launch(c, width, height, depth, 0, 0, c->samples_per_pixel, nullptr, c->samples_per_pixel,
                 reinterpret_cast<unsigned long long *>(counts));

@@ -43,6 +43,7 @@ SYMBOLS = [
     ("tdt_buffer_destroy", None, [_P]),
     ("tdt_bind_buffer_base", _I, [_P, _I, _U, _P]),
     ("tdt_buffer_sub_data", _I, [_P, _S, _S, _P]),
+    ("tdt_buffer_read", _I, [_P, _S, _S, _P]),
     ("tdt_image_create_rgba32f", _I, [_P, _I, _I, _PP]),
     ("tdt_image_wrap_device", _I, [_P, _P, _I, _I, _PP]),
     ("tdt_image_destroy", None, [_P]),
@@ -148,6 +149,11 @@ class VertexBufferObject:
     def sub_data(self, offset, data):
         a = np.ascontiguousarray(data)
         self.ctx.check(lib().tdt_buffer_sub_data(self.h, offset, a.nbytes, a.ctypes.data))
+
+    def read(self, dtype=np.uint32):
+        out = np.empty(self.nbytes // np.dtype(dtype).itemsize, dtype)
+        self.ctx.check(lib().tdt_buffer_read(self.h, 0, out.nbytes, out.ctypes.data))
+        return out
 
 
 class Texture:
@@ -278,6 +284,20 @@ def initial_uniforms(camera, program):
     program.set_vector3_f32("camera.origin", camera.origin)
     program.set_i32("camera.samples_per_pixel", camera.samples_per_pixel)
     program.set_i32("camera.max_bounce", camera.max_bounce)
+
+
+def update_vbo(ctx, delta_vbo, delta, length, update_compute):
+    """Octree::update_vbo (octree.rs:170-183): BufferSubData of `length` floats, then the oddly shaped
+    dispatch — (0, n, 0) unless n / 1024 is integral, n = (length as f32 * 0.2) as i32."""
+    d = np.ascontiguousarray(delta, np.float32)[:length]
+    delta_vbo.sub_data(0, d)
+    x_schedule = np.float32(length) * np.float32(0.2)
+    dispatch_count = int(x_schedule)
+    q = x_schedule / np.float32(32.0 * 32.0)
+    if q - np.trunc(q) != 0:
+        update_compute.dispatch_compute(0, dispatch_count, 0)
+    else:
+        update_compute.dispatch_compute(dispatch_count, 1, 1)
 
 
 def upload_scene(ctx, scene):

@@ -29,7 +29,7 @@ def _camera(meta):
     aspect = float(np.float32(meta["W"]) / np.float32(meta["H"]))
     return host.camera_build(90.0, meta["W"], aspect_ratio=aspect, viewport_height=2.0, origin=meta["origin"],
                              samples_per_pixel=meta["spp"], max_bounce=meta["max_bounce"])
-CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if "math_table" not in p)
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if "math_table" not in p and not os.path.basename(p).startswith("edit_"))
 
 
 def _eq(a, b):
@@ -197,8 +197,13 @@ def test_error_behaviour():
             cs.dispatch_compute(33, 33, 1)                                    # nothing bound
         assert e.value.code == rt.ERR_INCOMPLETE
         with pytest.raises(rt.TdtError) as e:
-            rt.ComputeShader(ctx, rt.PROGRAM_OCTREE_UPDATE)
+            rt.ComputeShader(ctx, 7)                                           # no such program
         assert e.value.code == rt.ERR_INVALID_ENUM
+        upd = rt.ComputeShader(ctx, rt.PROGRAM_OCTREE_UPDATE)                 # main.rs:226-230
+        assert upd.group_size == [1, 1, 1]
+        with pytest.raises(rt.TdtError) as e:
+            upd.dispatch_compute(0, 1, 0)                                     # nothing bound
+        assert e.value.code == rt.ERR_INCOMPLETE
         vbo = rt.VertexBufferObject(ctx, np.zeros(4, np.float32))
         with pytest.raises(rt.TdtError) as e:
             ctx.bind_buffer_base(rt.SHADER_STORAGE_BUFFER, 9, vbo)
