@@ -5,6 +5,7 @@
 // per-pixel trace of assets/shaders/raytracer.comp.  There is no CPU path in this library.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -794,8 +795,8 @@ int tdt_buffer_create(tdt_ctx *ctx, const void *data, size_t bytes, tdt_buffer *
   tdt_buffer *b = new (std::nothrow) tdt_buffer();
   if (!b) return fail(ctx, TDT_ERR_HIP, "out of host memory");
   b->ctx = ctx; b->bytes = bytes; b->dev = nullptr;
-  static unsigned long long next_version = 1;
-  b->version = next_version++;
+  static std::atomic<unsigned long long> next_version{1};   // contexts may live on different threads
+  b->version = next_version.fetch_add(1);
   std::memset(b->shadow, 0, sizeof b->shadow);
   TDT_HIP(ctx, hipSetDevice(ctx->device));
   // 16 bytes of zero slack so that the widest load at the last valid dword stays inside the allocation
