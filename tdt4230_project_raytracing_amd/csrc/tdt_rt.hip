@@ -20,6 +20,10 @@
 #ifndef TDT_MIN_WAVES
 #define TDT_MIN_WAVES 4
 #endif
+#ifndef TDT_BLOCK
+#define TDT_BLOCK 1024      // threads per persistent block; TDT_BLOCKS_PER_CU of them share a CU
+#define TDT_BLOCKS_PER_CU 1
+#endif
 // ============================================================================ kernels ======
 namespace tdt {
 
@@ -68,9 +72,9 @@ enum : int { ST_TRAVERSE = 0, ST_HIT = 1, ST_END = 2, ST_FETCH = 3, ST_PRIMARY =
 // COUNT: instrumented build that also totals the events defining the algorithmic bytes.
 // POW2: exact-comparison treeLookup (see tree_lookup_pow2) vs the literal float form.
 template <int MODE, bool COUNT, bool POW2, int DEPTH = 0, bool RESIDENT = false, bool SAFEV = false>
-__global__ __launch_bounds__(1024) void trace_kernel(const TraceParams P) {
+__global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   __shared__ __attribute__((aligned(16))) uint16_t s_nodes[kLdsCells * 8];
-  for (uint32_t i = threadIdx.x * 8u; i < P.lds_nodes; i += 1024u * 8u)      // one cell (8 x u16) per lane and trip
+  for (uint32_t i = threadIdx.x * 8u; i < P.lds_nodes; i += (uint32_t)TDT_BLOCK * 8u)      // one cell (8 x u16) per lane and trip
     *reinterpret_cast<uint4 *>(&s_nodes[i]) = *reinterpret_cast<const uint4 *>(&P.packed[i]);
   __syncthreads();
   NodeSource ns;
@@ -610,8 +614,8 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
   if (t.owned > 0) {
     // trace: one persistent block per CU (fewer when there is less work than lanes); resolve: a thread per pixel
     unsigned nblk = (unsigned)(((long)t.owned * 1024 + 1023) / 1024);
-    if (nblk > (unsigned)ctx->num_cus) nblk = (unsigned)ctx->num_cus;
-    dim3 grid(nblk, 1, 1), block(1024, 1, 1), grid4((unsigned)t.owned * 4u, 1, 1), block4(256, 1, 1);
+    if (nblk > (unsigned)ctx->num_cus * TDT_BLOCKS_PER_CU) nblk = (unsigned)ctx->num_cus * TDT_BLOCKS_PER_CU;
+    dim3 grid(nblk, 1, 1), block(TDT_BLOCK, 1, 1), grid4((unsigned)t.owned * 4u, 1, 1), block4(256, 1, 1);
     // the exact-comparison form of treeLookup needs cell_count = 2^k <= 2^22 and inv_cell_count = 2^-k
     // bit-for-bit (true for every scene Octree::init_global_buffers builds from such a count,
     // octree.rs:49); anything else (e.g. the demo scene's 100000) takes the literal float form

@@ -138,7 +138,10 @@ TDT_DEV uint32_t ld_dw(const uint32_t *buf, uint32_t dwords, uint32_t byte_off) 
 // fit in 14 bits, read the original).  Everything else comes from the linearised octree in HBM / L2 through
 // a raw buffer descriptor whose range check IS the reference's robust-access rule (reads past the
 // end return 0), so there is no bounds branch.
-constexpr uint32_t kLdsCells = 5120;                 // 5120 cells * 8 nodes * 2 B = 81,920 B of the 160 KiB LDS
+#ifndef TDT_LDS_CELLS
+#define TDT_LDS_CELLS 5120
+#endif
+constexpr uint32_t kLdsCells = TDT_LDS_CELLS;        // 5120 cells * 8 nodes * 2 B = 81,920 B of the 160 KiB LDS
 constexpr uint32_t kPackedEscape = 0xFFFFu;
 constexpr uint32_t kPackedMaxValue = 0x3FFEu;        // largest value an LDS entry can hold
 

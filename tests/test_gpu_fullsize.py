@@ -11,8 +11,9 @@ from tdt4230_project_raytracing_amd import host, rt, tiles
 
 pytestmark = pytest.mark.gpu
 
-# config -> (W, H, spp, max_bounce): configs[1] as stated; configs[2] / configs[4] at reduced spp (time)
-FULL = {2: (1920, 1080, 16, 8), 3: (3840, 2160, 4, 16), 5: (1920, 1080, 8, 8)}
+# config -> (W, H, spp, max_bounce): configs[1] as stated; configs[2] / [3] (the 8K frame of the 8-GPU config, here on
+# one GPU) / [4] at reduced spp (time)
+FULL = {2: (1920, 1080, 16, 8), 3: (3840, 2160, 4, 16), 4: (7680, 4320, 2, 8), 5: (1920, 1080, 8, 8)}
 
 
 def digest(img):
