@@ -165,7 +165,8 @@ int tdt_dispatch_counted(tdt_compute *c, int width, int height, int depth, uint6
  * csrc/trace_device.hpp `Counters`); development aid */
 int tdt_debug_counters(tdt_ctx *ctx, uint64_t out[32]);
 /* exhaustive (all 2^32 inputs) check of the kernels' short correctly-rounded rcp (0) / sqrt (1) /
- * rsq (2) forms against the IEEE expressions; *mismatches must be 0 */
+ * rsq (2) forms against the IEEE expressions and of v_fract_f32 against x - floor(x) for x >= 0 (4);
+ * *mismatches must be 0 (mode 3 checks the harness: the raw reciprocal seed must fail) */
 int tdt_selftest(tdt_ctx *ctx, int which, uint64_t *mismatches);
 
 #ifdef __cplusplus

@@ -362,7 +362,8 @@ __global__ __launch_bounds__(256) void selftest_kernel(int which, unsigned long 
     if (which == 0) { a = q_rcp(x); b = 1.0f / x; }
     else if (which == 1) { a = q_sqrt(x); b = __builtin_sqrtf(x); }
     else if (which == 2) { a = q_rsq(x); b = 1.0f / __builtin_sqrtf(x); }
-    else { a = __builtin_amdgcn_rcpf(x); b = 1.0f / x; }      // harness check: the raw hardware seed must NOT pass
+    else if (which == 3) { a = __builtin_amdgcn_rcpf(x); b = 1.0f / x; }      // harness check: the raw hardware seed must NOT pass
+    else { b = x - __builtin_floorf(x); a = (x >= 0.0f) ? __builtin_amdgcn_fractf(x) : b; }   // v_fract_f32 vs x - floor(x), x >= 0
     const bool same = (__float_as_uint(a) == __float_as_uint(b)) || (a != a && b != b);
     bad += same ? 0u : 1u;
   }
@@ -1020,7 +1021,7 @@ int tdt_debug_counters(tdt_ctx *ctx, uint64_t out[32]) {
 /* Exhaustive self-test of the kernels' short correctly-rounded rcp / sqrt / rsq forms against the
  * IEEE expressions on all 2^32 inputs; *mismatches must come back 0 (which: 0 rcp, 1 sqrt, 2 rsq). */
 int tdt_selftest(tdt_ctx *ctx, int which, uint64_t *mismatches) {
-  if (!ctx || !mismatches || which < 0 || which > 3) return TDT_ERR_INVALID_VALUE;
+  if (!ctx || !mismatches || which < 0 || which > 4) return TDT_ERR_INVALID_VALUE;
   TDT_HIP(ctx, hipSetDevice(ctx->device));
   if (!ctx->counters) TDT_HIP(ctx, hipMalloc((void **)&ctx->counters, 32 * sizeof(unsigned long long)));
   TDT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));

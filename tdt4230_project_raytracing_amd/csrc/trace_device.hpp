@@ -17,6 +17,9 @@ namespace tdt {
 #define TDT_DEV __device__ __forceinline__
 
 TDT_DEV float f_fract(float x) { return x - __builtin_floorf(x); }
+// for x >= 0 the v_fract_f32 instruction returns exactly x - floor(x) (checked on all inputs by
+// tdt_selftest mode 4); negative arguments keep the two-instruction form (they differ: fract(-tiny) = 1.0)
+TDT_DEV float f_fract_nonneg(float x) { return __builtin_amdgcn_fractf(x); }
 TDT_DEV float f_rcp(float x) { return 1.0f / x; }                          // IEEE-rounded
 TDT_DEV float f_rsq(float x) { return 1.0f / __builtin_sqrtf(x); }          // two roundings, as the reference
 
@@ -291,6 +294,7 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
   Zi = (Zf == Zfl) ? (Zi & (Zi - 1u)) : Zi;
   uint32_t qx = 0, v = 0, code = 1u;
   int m = 0;                                          // levels visited
+  const float fx0 = fx;
   auto level = [&](int l, uint32_t *mkey, uint32_t *mval) {    // l = 1-based level
     const int sh = depth - l;
     const float fv = (float)v;
@@ -334,8 +338,7 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
       }
     }
     m = l;
-    const float x2 = fx + fx;
-    fx = (fx >= 0.5f) ? x2 - 1.0f : x2;
+    fx = f_fract_nonneg(fx0 * __uint_as_float((uint32_t)(127 + l) << 23));   // fract(c * 2^l): next level's coordinate
   };
 #pragma unroll
   for (int l = 1; l <= kMemoFirst; l++) {
@@ -486,12 +489,13 @@ TDT_DEV bool scatter(const TraceParams &P, const Ray &r, const Hit &h, Ray &out,
 TDT_DEV Ray primary_ray(const TraceParams &P, int px, int py, int s) {
   float x = (float)px, y = (float)py, fs = (float)s;
   const float K = 0.2f * .1031f;
-  float a = f_fract(K * (x + fs)), b = f_fract(K * y);
+  // pixel coordinates and sample indices are non-negative, so every fract argument here is too
+  float a = f_fract_nonneg(K * (x + fs)), b = f_fract_nonneg(K * y);
   float d = (a + 33.33f) * (a + b) + a * (b + 33.33f);
-  float h1 = f_fract(((a + d) + (b + d)) * (a + d));
-  float a2 = f_fract(K * x), b2 = f_fract(K * (y + fs));
+  float h1 = f_fract_nonneg(((a + d) + (b + d)) * (a + d));
+  float a2 = f_fract_nonneg(K * x), b2 = f_fract_nonneg(K * (y + fs));
   float d2 = (a2 + 33.33f) * (a2 + b2) + a2 * (b2 + 33.33f);
-  float h2 = f_fract(((a2 + d2) + (b2 + d2)) * (a2 + d2));
+  float h2 = f_fract_nonneg(((a2 + d2) + (b2 + d2)) * (a2 + d2));
   float u = (x + h1) / (float)(P.image_width - 1);
   float v = (y + h2) / (float)(P.image_height - 1);
   float rx = (P.hor[0] * u + P.llc[0]) + (v * P.ver[0] + -P.org[0]);

@@ -236,3 +236,4 @@ def test_short_rounding_forms_exhaustively():
         assert ctx.selftest(1) == 0      # sqrt(x)
         assert ctx.selftest(2) == 0      # 1/sqrt(x), two roundings
         assert ctx.selftest(3) > 1000000
+        assert ctx.selftest(4) == 0      # v_fract_f32 == x - floor(x) for every x >= 0
