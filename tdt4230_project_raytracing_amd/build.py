@@ -51,5 +51,17 @@ def build_device(force=False, extra_flags=()):
     return out
 
 
+def build_demo(force=False):
+    """tdt_demo: the reference's main.rs, headless, written against include/renderer.hpp (C++ host mirror)."""
+    out = os.path.join(_HERE, "tdt_demo")
+    srcs = [os.path.join(CSRC, "demo_main.cpp"), os.path.join(INCLUDE, "renderer.hpp"), os.path.join(INCLUDE, "tdt_rt.h"),
+            os.path.join(INCLUDE, "tdt_host.h"), os.path.abspath(__file__)]
+    if force or _newer(out, srcs):
+        rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(HIPCC))), "lib")
+        _run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-I", INCLUDE, srcs[0], "-o", out, "-L", _HERE, "-ltdtrt", "-ltdthost",
+              "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + rocm_lib])
+    return out
+
+
 def build_all(force=False):
-    return build_host(force), build_device(force)
+    return build_host(force), build_device(force), build_demo(force)
