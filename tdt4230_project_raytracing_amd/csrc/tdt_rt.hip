@@ -73,9 +73,10 @@ enum : int { ST_TRAVERSE = 0, ST_HIT = 1, ST_END = 2, ST_FETCH = 3, ST_PRIMARY =
 // POW2: exact-comparison treeLookup (see tree_lookup_pow2) vs the literal float form.
 template <int MODE, bool COUNT, bool POW2, int DEPTH = 0, bool RESIDENT = false, bool SAFEV = false>
 __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
-  __shared__ __attribute__((aligned(16))) uint16_t s_nodes[kLdsCells * 8];
+  __shared__ __attribute__((aligned(16))) uint16_t s_nodes[kLdsCells * 8 + 8];   // + the sentinel slot
   for (uint32_t i = threadIdx.x * 8u; i < P.lds_nodes; i += (uint32_t)TDT_BLOCK * 8u)      // one cell (8 x u16) per lane and trip
     *reinterpret_cast<uint4 *>(&s_nodes[i]) = *reinterpret_cast<const uint4 *>(&P.packed[i]);
+  if (threadIdx.x == 0) s_nodes[P.lds_nodes] = (uint16_t)((RESIDENT && POW2) ? 0u : kPackedEscape);
   __syncthreads();
   NodeSource ns;
   ns.lds = s_nodes; ns.lds_nodes = P.lds_nodes;

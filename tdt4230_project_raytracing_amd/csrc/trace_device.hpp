@@ -157,8 +157,8 @@ struct NodeSource {
 // returns the node's value; code = 0 EMPTY, 2 LEAF, 1 otherwise (rc:384-386 only distinguishes these)
 TDT_DEV uint32_t fetch_node(const NodeSource &ns, uint32_t idx, uint32_t &code) {
   idx &= 0x1FFFFFFFu;                                 // byte offset idx << 3 wraps at 32 bits (rc:184 on a 32-bit offset)
-  if (idx < ns.lds_nodes) {
-    const uint32_t n = ns.lds[idx];
+  {
+    const uint32_t n = ns.lds[idx < ns.lds_nodes ? idx : ns.lds_nodes];     // sentinel slot: see tree_lookup_pow2
     if (n != kPackedEscape) { code = n & 3u; return n >> 2; }
   }
   const auto n2 = __builtin_amdgcn_raw_buffer_load_b64(ns.cells, (int)(idx << 3), 0, 0);
@@ -319,11 +319,12 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
     qx = (qx << 1) | bitx;
     const uint32_t idx = ((ix << 2) + (((Yi >> sh) & 1u) << 1) + ((Zi >> sh) & 1u)) & 0x1FFFFFFFu;
     if (COUNT) { cnt.level_slots += slot64(); cnt.level_active++; cnt.node_loads++; }
-    // LDS table first (unconditional read of a clamped index: no branch for resident nodes)
-    const uint32_t li = idx < ns.lds_nodes ? idx : 0u;
-    uint32_t n = ns.lds[li];
-    if (RESIDENT) n = idx < ns.lds_nodes ? n : 0u;      // past the end of the buffer: reads 0 = EMPTY (robust access)
-    const bool resident = RESIDENT || ((idx < ns.lds_nodes) & (n != kPackedEscape));
+    // LDS table first: an unconditional read of min(idx, lds_nodes).  The slot just past the table holds
+    // a sentinel: EMPTY (0) when the whole buffer is resident — a read past the end of the buffer IS 0
+    // (robust access) — and the escape code otherwise, which sends the lane to the range-checked HBM path.
+    const uint32_t li = idx < ns.lds_nodes ? idx : ns.lds_nodes;
+    const uint32_t n = ns.lds[li];
+    const bool resident = RESIDENT || (n != kPackedEscape);
     v = n >> 2; code = n & 3u;
     if (!resident) {
       if (mkey && (*mkey & 0x1FFFFFFFu) == idx) {
