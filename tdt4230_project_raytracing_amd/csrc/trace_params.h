@@ -22,6 +22,8 @@ struct TraceParams {
   float *carry;
   unsigned long long *counters; // instrumented launches only: event totals (see Counters)
   unsigned int *queue;          // global pixel queue head (zeroed before every launch)
+  const uint32_t *tile_order;   // owned work-group indices, most expensive first (from the previous dispatch), or null
+  uint32_t *tile_cost;          // per owned work-group: summed pixel times of THIS dispatch (feeds the next one), or null
   const uint16_t *packed;       // cells [0, lds_cells) re-encoded as 16 bits per node: value << 2 | code
   uint32_t lds_nodes;           // number of nodes (8 per cell) staged in LDS by every block
   int32_t compact;             // 1: image is this rank's tile buffer [owned tile k][32][32] RGBA

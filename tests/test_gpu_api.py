@@ -171,6 +171,27 @@ def test_unspecialised_kernel_equals_specialised(oracle, monkeypatch, cfg, W, H)
         r.close()
 
 
+def test_cost_feedback_order_changes_only_the_schedule(oracle, monkeypatch):
+    """From the second dispatch of a context on, work-groups of an LDS-resident scene are handed out most
+    expensive first (costs measured by the previous dispatch).  Every frame must still be the same bits."""
+    scene = host.Scene.config(2)
+    cam = host.camera_reference_pose(320, 192, 3, 8)
+    ref = oracle.render(scene, cam, threads=8)
+    r = rt.Renderer(scene, cam)
+    try:
+        for _ in range(3):                      # image order, then twice in cost order
+            assert _eq(r.render(), ref)
+    finally:
+        r.close()
+    monkeypatch.setenv("TDT_NO_COST_ORDER", "1")
+    r = rt.Renderer(scene, cam)
+    try:
+        for _ in range(2):
+            assert _eq(r.render(), ref)
+    finally:
+        r.close()
+
+
 def test_zero_samples_and_zero_bounces(oracle):
     scene = host.Scene.demo()
     for spp, bounce in ((0, 4), (2, 0)):
