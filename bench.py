@@ -200,8 +200,9 @@ def main():
                        "image": [IW, IH], "dispatch": [dw, dh, 1], "written_pixels": int(total_pixels), "spp": spp,
                        "max_bounce": bounce, "octree_max_depth": scene.max_depth, "octree_cells": scene.counts["cells"],
                        "scene_bytes": scene.nbytes(),
-                       "schedule": "global pixel queue; work-groups of an LDS-resident tree handed out most-expensive-first from the "
-                                   "previous dispatch's measured costs (TDT_NO_COST_ORDER=1: image order)",
+                       "schedule": "global pixel queue; pixels handed out most-expensive-first from the work counts (tree levels, "
+                                   "steps, path events) the previous dispatch recorded per pixel; the first dispatch of a "
+                                   "context runs in image order (TDT_NO_COST_ORDER=1: always)",
                        "partition": f"32x32 work-groups dealt round-robin over {world} rank(s)" + ("; one RCCL gather + de-interleave per step" if sharded else "")},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,

@@ -164,6 +164,13 @@ int tdt_dispatch_counted(tdt_compute *c, int width, int height, int depth, uint6
 /* lane-utilisation diagnostics of the last tdt_dispatch_counted of this context (32 totals; layout in
  * csrc/trace_device.hpp `Counters`); development aid */
 int tdt_debug_counters(tdt_ctx *ctx, uint64_t out[32]);
+/* development aids, filled by tdt_dispatch_counted (tools/timeline.py, tools/pixel_log.py):
+ * wave_ends: n <= 16384 + 256 entries — per-wave end times (100 MHz ticks; index = block * 16 + wave), then from
+ * entry 16384 two 128-bin histograms (0.1 ms bins) of pixel durations: pixels finished while the queue still had
+ * work / by waves that had seen its end.  pixel_log (only when TDT_PIXEL_LOG is set in the environment): 8 u32
+ * per queue slot — traversal steps, path events, wave passes, start tick, end tick, wave, event passes, threshold. */
+int tdt_debug_wave_ends(tdt_ctx *ctx, uint64_t *out, int n);
+int tdt_debug_pixel_log(tdt_ctx *ctx, uint32_t *out, size_t n_u32);
 /* exhaustive (all 2^32 inputs) check of the kernels' short correctly-rounded rcp (0) / sqrt (1) /
  * rsq (2) forms against the IEEE expressions and of v_fract_f32 against x - floor(x) for x >= 0 (4);
  * *mismatches must be 0 (mode 3 checks the harness: the raw reciprocal seed must fail) */

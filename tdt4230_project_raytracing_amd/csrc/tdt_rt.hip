@@ -84,6 +84,9 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   const uint32_t total_slots = (uint32_t)P.owned_tiles * 1024u;
 
   const float inf = __builtin_inff();
+  unsigned long long pixel_rt0 = 0ull; bool wave_drained = false; uint32_t lane_S = 0, lane_E = 0, pass_no = 0, pixel_pass0 = 0, evpass_no = 0, pixel_evpass0 = 0;
+  const unsigned long long wave_t0 = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  if (COUNT && (threadIdx.x & 63) == 0) atomicCAS(&P.counters[23], 0ull, wave_t0);   // time base of the pixel log   // 100 MHz, same on every XCD
   Counters cnt = {};
   uint32_t n_pixels = 0;
   NodeMemo<kMemoLevels> memo;
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
 
   int state = ST_FETCH;
   int x = 0, y = 0; size_t pix = 0;
-  uint32_t pixel_k = 0, pixel_t0 = 0;               // work-group of the current pixel and when it was started
+  uint32_t pixel_slot = 0, pixel_t0 = 0;            // queue slot (work-group * 1024 + pixel) of the current pixel and when it was started
   int s = 0, loop_count = 0;
   Ray r = {0.f, 0.f, 0.f, 0.f, 0.f, 1.f};
   float ix = 0.f, iy = 0.f, iz = 0.f;                // 1 / direction (ray-invariant, rc:319)
@@ -108,13 +111,18 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
 
   // adaptive event threshold (wave-uniform): the more traversal work a ray is, the less it pays to
   // keep finished lanes waiting for company before running the event code.  Measured optima over
-  // the BASELINE scenes fit  threshold ~ K / (traversal steps per ray * max_depth),  K ~ 1600.
-  uint32_t w_steps = 0, w_rays = 0;
+  // the BASELINE scenes fit  threshold ~ K / (traversal steps per ray * max_depth),  K ~ 2400 (1600 before
+  // pixels were handed out in cost order).  The counts are a sliding window (kEventWindow rays): in cost order
+  // a wave meets the expensive pixels first and the sky last, and a threshold learnt on the former made the
+  // latter run the event code on every pass.
+  uint32_t w_steps = 0, w_rays = 0, lane_work = 0;
   int threshold = P.event_threshold > 0 ? P.event_threshold : 24;
 
   for (;;) {
+    if (COUNT) pass_no++;
     // ------------------------------------------------------------ one traversal step rc:410-447
     if (state == ST_TRAVERSE) {
+      if (COUNT) lane_S++;
       if (COUNT) { cnt.trav_slots += slot64(); cnt.trav_active++; }
       if (!(it < P.max_iter && t_stride < t_octree_max)) {
         state = ST_END;                               // OctreeHit returns false rc:449
@@ -138,6 +146,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
           if (COUNT) cnt.iterations++;
           const bool leaf = POW2 ? tree_lookup_pow2<COUNT, kMemoLevels, DEPTH, RESIDENT, SAFEV>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, memo, cnt)
                                  : tree_lookup<COUNT>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, cnt);
+          lane_work += kCostStep + (127u - (__float_as_uint(inv_pow_depth) >> 23));   // + tree levels visited (inv_pow_depth = 2^-levels)
           const float bx = ugx * P.scale + P.min_x, by = ugy * P.scale + P.min_y, bz = ugz * P.scale + P.min_z;
           const float cs0 = P.scale * inv_pow_depth;
           // leaf: the exact cell (rc:427-428); empty: padded by -1e-5 / +2e-5 (rc:441-442)
@@ -168,9 +177,16 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     w_steps += (uint32_t)__popcll(m_trav);            // lanes that take the next traversal step
     // run the (long, material-divergent) event code only when enough lanes wait for it (a separate
     // threshold for scatter alone was measured: worse at every setting)
-    if (__popcll(m_event) < threshold && m_trav != 0ull) continue;
+    // once the queue has run dry lanes retire (ST_DONE) and only latency is left to win: scale the threshold
+    // with the lanes still alive so that the survivors do not wait for company that will never come
+    const int n_alive = __popcll(m_trav | m_event);
+    const int th_now = n_alive == 64 ? threshold : ((threshold * n_alive) >> 6) + 1;
+    if (__popcll(m_event) < th_now && m_trav != 0ull) continue;
 
+    if (COUNT) evpass_no++;
     if (COUNT) { cnt.event_slots += slot64(); cnt.event_active += (state != ST_TRAVERSE && state != ST_DONE); }
+    lane_work += (state != ST_TRAVERSE && state != ST_DONE) ? kCostEvent : 0u;
+    if (COUNT) lane_E += (state != ST_TRAVERSE && state != ST_DONE) ? 1u : 0u;
     if (state == ST_HIT) {                            // RayColor loop body rc:272-295
       if (COUNT) { cnt.scatter_slots += slot64(); cnt.scatter_active++; }
       if (leaf_rec) { cube_hit_record(r, t_stride, leaf_box_x, leaf_box_y, leaf_box_z, inv_pow_depth, pc.leaf); if (COUNT) cnt.leaf_records++; }
@@ -219,7 +235,16 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
           o.w = 1.0f;
           *dst = o;
         }
-        if (P.tile_cost) atomicAdd(&P.tile_cost[pixel_k], ((uint32_t)__builtin_readcyclecounter() - pixel_t0) >> 8);
+        if (COUNT && P.pixel_log) {
+          uint32_t *L = P.pixel_log + (size_t)pixel_slot * 8;
+          L[0] = lane_S; L[1] = lane_E; L[2] = pass_no - pixel_pass0; L[3] = (uint32_t)(pixel_rt0 - P.counters[23]);
+          L[4] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - P.counters[23]); L[5] = blockIdx.x * 16 + (threadIdx.x >> 6); L[6] = evpass_no - pixel_evpass0; L[7] = (uint32_t)threshold;
+        }
+        if (COUNT) {
+          const unsigned long long d = (__builtin_amdgcn_s_memrealtime() - pixel_rt0) / 10000ull;   // 0.1 ms bins
+          atomicAdd(&P.counters[32 + 16384 + (wave_drained ? 128 : 0) + (d > 127ull ? 127ull : d)], 1ull);
+        }
+        if (P.slot_cost) P.slot_cost[pixel_slot] = lane_work | 1u;
         state = ST_FETCH;
       }
     }
@@ -230,14 +255,16 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
         uint32_t base = 0;
         if ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(P.queue, (uint32_t)__popcll(m));
         base = (uint32_t)__shfl((int)base, __builtin_ctzll(m), 64);
+        if (COUNT && base + 64u > total_slots) wave_drained = true;
         if (want) {
           const uint32_t q = base + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
-          if (q >= total_slots) state = ST_DONE;
+          if (q >= total_slots) { state = ST_DONE; if (COUNT) atomicMin(&P.counters[22], __builtin_amdgcn_s_memrealtime()); }
           else {
+            if (COUNT) { pixel_rt0 = __builtin_amdgcn_s_memrealtime(); lane_S = 0; lane_E = 0; pixel_pass0 = pass_no; pixel_evpass0 = evpass_no; }
             bool inside;
-            pixel_k = P.tile_order ? P.tile_order[q >> 10] : (q >> 10);
-            decode_pixel(P, (int)pixel_k, q & 1023u, x, y, pix, inside);
-            pixel_t0 = (uint32_t)__builtin_readcyclecounter();
+            pixel_slot = P.slot_order ? P.slot_order[q] : q;
+            decode_pixel(P, (int)(pixel_slot >> 10), pixel_slot & 1023u, x, y, pix, inside);
+            lane_work = 0u;
             if (inside) {                             // outside the covered image: ask again next time
               n_pixels++;
               sr = 0.f; sg = 0.f; sb = 0.f; s = P.spp_begin;
@@ -270,7 +297,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     }
     w_rays += (uint32_t)__popcll(__ballot(state == ST_NEWRAY));
     if (P.event_threshold <= 0) {
-      if (w_steps > (1u << 28)) { w_steps >>= 1; w_rays >>= 1; }
+      if (w_rays > kEventWindow) { w_steps >>= 1; w_rays >>= 1; }   // sliding window: the mix of pixels a wave sees changes over a frame
       const float est = P.event_k * (float)w_rays / ((float)w_steps * (float)P.max_depth + 1.0f);
       const int th = (int)est;
       threshold = w_rays < 256u ? 24 : (th < 2 ? 2 : (th > 40 ? 40 : th));
@@ -302,6 +329,13 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   }
 
   if (COUNT) {
+    // wave timeline (diagnostics): [18] earliest start, [19] latest end, [20] sum of wave end times, [21] waves
+    if ((threadIdx.x & 63) == 0) {
+      const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+      atomicMin(&P.counters[18], wave_t0); atomicMax(&P.counters[19], t_end);
+      atomicAdd(&P.counters[20], t_end - wave_t0); atomicAdd(&P.counters[21], 1ull);
+      P.counters[32 + blockIdx.x * (TDT_BLOCK / 64) + (threadIdx.x >> 6)] = t_end;   // per-wave end time (grid <= 256 blocks... see kWaveLog)
+    }
     uint32_t v[18] = {n_pixels, cnt.octree_hit_calls, cnt.iterations, cnt.node_loads,
                       cnt.lambertian, cnt.metal, cnt.dielectric, cnt.unknown,
                       cnt.trav_slots, cnt.trav_active, cnt.level_slots, cnt.level_active, cnt.event_slots, cnt.event_active,
@@ -418,33 +452,56 @@ __global__ __launch_bounds__(64) void octree_update_kernel(uint32_t *cells, uint
   }
 }
 
-// Cost-feedback scheduling.  A lane owns a pixel for all of its samples (they are sequential), so a frame
-// ends with a tail as long as the most expensive pixel that was started late — 13 % of a 1080p/64 spp frame
-// when work-groups are handed out in image order.  The trace kernel records how long each of its pixels
-// took (summed per 32x32 work-group); this kernel turns those costs into the hand-out order of the NEXT
-// dispatch, most expensive first, so the frame ends on the cheapest pixels.  Like a renderer's render
-// loop (main.rs:486-601) the assumption is that consecutive frames cost about the same per region; the
-// first dispatch of a context, or one with a different number of work-groups, runs in image order.
-// Only the schedule changes: every pixel is computed exactly as before.
-// One block: counting sort by a 256-bin logarithmic cost key (8 bins per octave), descending.
-__global__ __launch_bounds__(1024) void order_tiles_kernel(uint32_t *__restrict__ cost, uint32_t *__restrict__ order, uint32_t n) {
+// Cost-feedback scheduling.  A lane owns a pixel for all of its samples (they are sequential) and a frame is
+// only ~8 pixels per lane, so in image order a frame ends with a long tail (the queue runs dry after 60-85 %
+// of the kernel) and its waves mix sky pixels with deep ones.  The trace kernel therefore records the work of
+// each of its pixels — tree levels visited + kCostStep per traversal step + kCostEvent per path event, counts
+// that depend on the pixel alone, not on which wave ran it (a pixel's wall time does, and ordering by it never
+// settles) — and these kernels turn the costs into the pixel hand-out order of the NEXT dispatch, most
+// expensive first: the frame ends on the cheapest pixels, and the pixels of a wave are alike, which also lets
+// the adaptive event threshold fit them.  Like a renderer's render loop (main.rs:486-601) the assumption is
+// that consecutive frames cost about the same per pixel; the first dispatch of a context, or one with a
+// different number of work-groups, runs in image order.  Only the schedule changes: every pixel is computed
+// exactly as before.  Measured (MI355X, steady state): 1080p/64 spp 64^3 38.1 -> 34.5 ms, 4K/64 spp 256^3
+// 437 -> 369 ms, 1080p/64 spp 512^3 288 -> 201 ms.
+// Counting sort by a 256-bin logarithmic cost key (8 bins per octave), descending, in two passes over chunks
+// of kOrderChunk slots: order_hist_kernel sums per-chunk LDS histograms into hist[256]; order_scatter_kernel
+// reserves each chunk's range of every bin with one atomic on cursor[bin] and scatters through LDS counters.
+constexpr uint32_t kOrderChunk = 8192;
+__device__ __forceinline__ uint32_t order_key(uint32_t c) {   // larger cost -> smaller key; never-run slots last
+  if (c == 0) return 255u;
+  const uint32_t e = 31u - (uint32_t)__builtin_clz(c);
+  const uint32_t frac = e >= 3 ? (c >> (e - 3)) & 7u : (c << (3 - e)) & 7u;
+  return 255u - (e * 8u + frac);
+}
+__global__ __launch_bounds__(1024) void order_hist_kernel(const uint32_t *__restrict__ cost, uint32_t n, uint32_t *__restrict__ hist) {
+  __shared__ uint32_t s_bin[256];
+  if (threadIdx.x < 256) s_bin[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t lo = blockIdx.x * kOrderChunk, hi = lo + kOrderChunk < n ? lo + kOrderChunk : n;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) atomicAdd(&s_bin[order_key(cost[i])], 1u);
+  __syncthreads();
+  if (threadIdx.x < 256 && s_bin[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_bin[threadIdx.x]);
+}
+__global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restrict__ cost, uint32_t n, const uint32_t *__restrict__ hist,
+                                                             uint32_t *__restrict__ cursor, uint32_t *__restrict__ order) {
   __shared__ uint32_t s_bin[256], s_base[256];
   if (threadIdx.x < 256) s_bin[threadIdx.x] = 0;
   __syncthreads();
-  auto key = [](uint32_t c) -> uint32_t {             // larger cost -> smaller key
-    if (c == 0) return 255u;
-    const uint32_t e = 31u - (uint32_t)__builtin_clz(c);
-    const uint32_t frac = e >= 3 ? (c >> (e - 3)) & 7u : (c << (3 - e)) & 7u;
-    const uint32_t k = e * 8u + frac;                  // 0..255
-    return 255u - k;
-  };
-  for (uint32_t i = threadIdx.x; i < n; i += 1024u) atomicAdd(&s_bin[key(cost[i])], 1u);
+  const uint32_t lo = blockIdx.x * kOrderChunk, hi = lo + kOrderChunk < n ? lo + kOrderChunk : n;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) atomicAdd(&s_bin[order_key(cost[i])], 1u);
   __syncthreads();
-  if (threadIdx.x == 0) { uint32_t acc = 0; for (int b = 0; b < 256; b++) { s_base[b] = acc; acc += s_bin[b]; } }
+  if (threadIdx.x < 256) {
+    uint32_t before = 0;
+    for (uint32_t b = 0; b < threadIdx.x; b++) before += hist[b];
+    const uint32_t mine = s_bin[threadIdx.x];
+    s_base[threadIdx.x] = before + (mine ? atomicAdd(&cursor[threadIdx.x], mine) : 0u);
+  }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < n; i += 1024u) order[atomicAdd(&s_base[key(cost[i])], 1u)] = i;
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < n; i += 1024u) cost[i] = 0;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) {
+    order[atomicAdd(&s_base[order_key(cost[i])], 1u)] = i;
+    cost[i] = 0;
+  }
 }
 
 // De-interleave gathered per-rank tile buffers ([rank][k][32][32] RGBA) into a W x H image.
@@ -496,8 +553,8 @@ struct tdt_ctx {
   uint16_t *packed;             // LDS-table image of the bound cells buffer
   const tdt_buffer *packed_of;  // which buffer/version `packed` was built from
   unsigned long long packed_version;
-  uint32_t *tile_cost, *tile_order;   // cost feedback of the last trace dispatch and the hand-out order derived from it
-  uint32_t tile_capacity, order_tiles; // allocation size; number of work-groups tile_order is valid for (0: none)
+  uint32_t *slot_cost, *slot_order, *order_hist;   // per queue slot: cost feedback of the last trace dispatch, the hand-out order derived from it; 2 x 256 sort counters
+  uint32_t tile_capacity, order_tiles; // allocation size (work-groups); number of work-groups slot_order is valid for (0: none)
   bool no_cost_order;           // TDT_NO_COST_ORDER=1: always hand work-groups out in image order
   uint32_t *scan;               // device scratch of scan_cells_kernel
   uint32_t max_parent_value, max_any_value;   // its result for `packed_of`
@@ -505,6 +562,7 @@ struct tdt_ctx {
   bool force_generic;   // TDT_FORCE_GENERIC=1: always run the literal-arithmetic kernel (A/B testing)
   int event_threshold;  // TDT_EVENT_THRESHOLD=n fixes the event threshold (experiments); 0 = adaptive
   float event_k;        // TDT_EVENT_K overrides the adaptive constant
+  uint32_t *pixel_log; size_t pixel_log_u32;   // TDT_PIXEL_LOG diagnostics (instrumented dispatches only)
   bool no_specialise;   // TDT_NO_SPECIALISE=1: never pick a scene-specialised kernel (A/B testing)
   std::vector<tdt_buffer *> buffers;
   std::vector<tdt_image *> images;
@@ -618,9 +676,18 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
   if (ctx->ssbo[TDT_SLOT_CELLS]->bytes > 0xFFFFFFF8ull)
     return fail(ctx, TDT_ERR_INVALID_VALUE, "cells buffer larger than 4 GiB is not addressable by the shader's 32-bit offsets");
   if (counts_out) {
-    if (!ctx->counters) TDT_HIP(ctx, hipMalloc((void **)&ctx->counters, 32 * sizeof(unsigned long long)));
+    if (!ctx->counters) TDT_HIP(ctx, hipMalloc((void **)&ctx->counters, (32 + 16384 + 256) * sizeof(unsigned long long)));
     TDT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, 32 * sizeof(unsigned long long), ctx->stream));
+    TDT_HIP(ctx, hipMemsetAsync(ctx->counters + 18, 0xFF, sizeof(unsigned long long), ctx->stream));   // running minima
+    TDT_HIP(ctx, hipMemsetAsync(ctx->counters + 22, 0xFF, sizeof(unsigned long long), ctx->stream));
+    TDT_HIP(ctx, hipMemsetAsync(ctx->counters + 32 + 16384, 0, 256 * sizeof(unsigned long long), ctx->stream));
     P.counters = ctx->counters;
+    if (getenv("TDT_PIXEL_LOG")) {
+      const size_t need = (size_t)t.owned * 1024 * 8;
+      if (ctx->pixel_log_u32 < need) { if (ctx->pixel_log) (void)hipFree(ctx->pixel_log); TDT_HIP(ctx, hipMalloc((void **)&ctx->pixel_log, need * 4)); ctx->pixel_log_u32 = need; }
+      TDT_HIP(ctx, hipMemsetAsync(ctx->pixel_log, 0, need * 4, ctx->stream));
+      P.pixel_log = ctx->pixel_log;
+    }
   }
   const uint32_t buf_nodes = P.cells_dwords >> 1;
   if (t.owned > 0 && mode != 2) {
@@ -647,26 +714,23 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
       ctx->packed_of = cb; ctx->packed_version = cb->version;
     }
     P.packed = ctx->packed; P.queue = ctx->queue;
-    // cost-feedback hand-out order (see order_tiles_kernel) — only when the whole tree sits in LDS: scenes that
-    // live in L2 / HBM gain more from handing neighbouring work-groups out together (measured: 256^3 and 512^3
-    // scenes are 2-3 % slower in cost order, the LDS-resident 64^3 scene 8 % faster)
-    const bool tree_in_lds = buf_nodes == P.lds_nodes && buf_nodes > 0 && (P.cells_dwords & 1u) == 0 &&
-                             ctx->max_any_value <= tdt::kPackedMaxValue;
-    if (!ctx->no_cost_order && tree_in_lds) {
+    // cost-feedback hand-out order (see order_scatter_kernel); TDT_NO_COST_ORDER=1: image order
+    if (!ctx->no_cost_order) {
       if (ctx->tile_capacity < (uint32_t)t.owned) {
-        if (ctx->tile_cost) (void)hipFree(ctx->tile_cost);
-        if (ctx->tile_order) (void)hipFree(ctx->tile_order);
-        ctx->tile_cost = ctx->tile_order = nullptr; ctx->tile_capacity = 0; ctx->order_tiles = 0;
-        TDT_HIP(ctx, hipMalloc((void **)&ctx->tile_cost, (size_t)t.owned * sizeof(uint32_t)));
-        TDT_HIP(ctx, hipMalloc((void **)&ctx->tile_order, (size_t)t.owned * sizeof(uint32_t)));
+        if (ctx->slot_cost) (void)hipFree(ctx->slot_cost);
+        if (ctx->slot_order) (void)hipFree(ctx->slot_order);
+        ctx->slot_cost = ctx->slot_order = nullptr; ctx->tile_capacity = 0; ctx->order_tiles = 0;
+        TDT_HIP(ctx, hipMalloc((void **)&ctx->slot_cost, (size_t)t.owned * 1024 * sizeof(uint32_t)));
+        TDT_HIP(ctx, hipMalloc((void **)&ctx->slot_order, (size_t)t.owned * 1024 * sizeof(uint32_t)));
+        if (!ctx->order_hist) TDT_HIP(ctx, hipMalloc((void **)&ctx->order_hist, 512 * sizeof(uint32_t)));
         ctx->tile_capacity = (uint32_t)t.owned;
       }
       if (ctx->order_tiles != (uint32_t)t.owned) {   // no usable history: image order, fresh cost array
         ctx->order_tiles = 0;
-        TDT_HIP(ctx, hipMemsetAsync(ctx->tile_cost, 0, (size_t)t.owned * sizeof(uint32_t), ctx->stream));
+        TDT_HIP(ctx, hipMemsetAsync(ctx->slot_cost, 0, (size_t)t.owned * 1024 * sizeof(uint32_t), ctx->stream));
       }
-      P.tile_cost = ctx->tile_cost;
-      P.tile_order = ctx->order_tiles ? ctx->tile_order : nullptr;
+      P.slot_cost = ctx->slot_cost;
+      P.slot_order = ctx->order_tiles ? ctx->slot_order : nullptr;
     }
     TDT_HIP(ctx, hipMemsetAsync(ctx->queue, 0, sizeof(unsigned int), ctx->stream));
   }
@@ -704,8 +768,12 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     else hipLaunchKernelGGL(tdt::resolve_kernel, grid4, block4, 0, ctx->stream, P);
 #undef TDT_LAUNCH
     TDT_HIP(ctx, hipGetLastError());
-    if (mode != 2 && P.tile_cost) {
-      hipLaunchKernelGGL(tdt::order_tiles_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->tile_cost, ctx->tile_order, (uint32_t)t.owned);
+    if (mode != 2 && P.slot_cost) {
+      const uint32_t n_slots = (uint32_t)t.owned * 1024u, n_chunks = (n_slots + tdt::kOrderChunk - 1) / tdt::kOrderChunk;
+      TDT_HIP(ctx, hipMemsetAsync(ctx->order_hist, 0, 512 * sizeof(uint32_t), ctx->stream));
+      hipLaunchKernelGGL(tdt::order_hist_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, n_slots, ctx->order_hist);
+      hipLaunchKernelGGL(tdt::order_scatter_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, n_slots,
+                         ctx->order_hist, ctx->order_hist + 256, ctx->slot_order);
       TDT_HIP(ctx, hipGetLastError());
       ctx->order_tiles = (uint32_t)t.owned;
     }
@@ -735,14 +803,14 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
   if (!ctx) return fail(nullptr, TDT_ERR_HIP, "out of host memory");
   ctx->device = device_id;
   for (auto &s : ctx->ssbo) s = nullptr;
-  ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr; ctx->queue = nullptr; ctx->packed = nullptr; ctx->packed_of = nullptr; ctx->packed_version = 0; ctx->tile_cost = ctx->tile_order = nullptr; ctx->tile_capacity = ctx->order_tiles = 0;
+  ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr; ctx->queue = nullptr; ctx->packed = nullptr; ctx->packed_of = nullptr; ctx->packed_version = 0; ctx->pixel_log = nullptr; ctx->pixel_log_u32 = 0; ctx->slot_cost = ctx->slot_order = ctx->order_hist = nullptr; ctx->tile_capacity = ctx->order_tiles = 0;
   { const char *nc = getenv("TDT_NO_COST_ORDER"); ctx->no_cost_order = nc && nc[0] == '1'; }
   ctx->scan = nullptr; ctx->max_parent_value = ctx->max_any_value = 0xFFFFFFFFu;
   { hipDeviceProp_t prop; ctx->num_cus = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
   { const char *fg = getenv("TDT_FORCE_GENERIC"); ctx->force_generic = fg && fg[0] == '1';
     const char *ns_ = getenv("TDT_NO_SPECIALISE"); ctx->no_specialise = ns_ && ns_[0] == '1';
     const char *et = getenv("TDT_EVENT_THRESHOLD"); ctx->event_threshold = et ? atoi(et) : 0;
-    const char *ek = getenv("TDT_EVENT_K"); ctx->event_k = ek ? (float)atof(ek) : 1600.0f; }
+    const char *ek = getenv("TDT_EVENT_K"); ctx->event_k = ek ? (float)atof(ek) : 2400.0f; }
   if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
   else {
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -764,8 +832,10 @@ void tdt_ctx_destroy(tdt_ctx *ctx) {
   if (ctx->queue) (void)hipFree(ctx->queue);
   if (ctx->packed) (void)hipFree(ctx->packed);
   if (ctx->scan) (void)hipFree(ctx->scan);
-  if (ctx->tile_cost) (void)hipFree(ctx->tile_cost);
-  if (ctx->tile_order) (void)hipFree(ctx->tile_order);
+  if (ctx->slot_cost) (void)hipFree(ctx->slot_cost);
+  if (ctx->slot_order) (void)hipFree(ctx->slot_order);
+  if (ctx->order_hist) (void)hipFree(ctx->order_hist);
+  if (ctx->pixel_log) (void)hipFree(ctx->pixel_log);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1084,13 +1154,26 @@ int tdt_debug_counters(tdt_ctx *ctx, uint64_t out[32]) {
   TDT_HIP(ctx, hipMemcpy(out, ctx->counters, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return TDT_OK;
 }
+int tdt_debug_pixel_log(tdt_ctx *ctx, uint32_t *out, size_t n_u32) {
+  if (!ctx || !out || !ctx->pixel_log || n_u32 > ctx->pixel_log_u32) return TDT_ERR_INVALID_VALUE;
+  TDT_HIP(ctx, hipSetDevice(ctx->device));
+  TDT_HIP(ctx, hipMemcpy(out, ctx->pixel_log, n_u32 * 4, hipMemcpyDeviceToHost));
+  return TDT_OK;
+}
+/* per-wave end times (100 MHz ticks) of the last instrumented dispatch: n <= 16384 entries */
+int tdt_debug_wave_ends(tdt_ctx *ctx, uint64_t *out, int n) {
+  if (!ctx || !out || !ctx->counters || n < 0 || n > 16384 + 256) return TDT_ERR_INVALID_VALUE;
+  TDT_HIP(ctx, hipSetDevice(ctx->device));
+  TDT_HIP(ctx, hipMemcpy(out, ctx->counters + 32, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return TDT_OK;
+}
 
 /* Exhaustive self-test of the kernels' short correctly-rounded rcp / sqrt / rsq forms against the
  * IEEE expressions on all 2^32 inputs; *mismatches must come back 0 (which: 0 rcp, 1 sqrt, 2 rsq). */
 int tdt_selftest(tdt_ctx *ctx, int which, uint64_t *mismatches) {
   if (!ctx || !mismatches || which < 0 || which > 4) return TDT_ERR_INVALID_VALUE;
   TDT_HIP(ctx, hipSetDevice(ctx->device));
-  if (!ctx->counters) TDT_HIP(ctx, hipMalloc((void **)&ctx->counters, 32 * sizeof(unsigned long long)));
+  if (!ctx->counters) TDT_HIP(ctx, hipMalloc((void **)&ctx->counters, (32 + 16384 + 256) * sizeof(unsigned long long)));
   TDT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));
   hipLaunchKernelGGL(tdt::selftest_kernel, dim3(4096), dim3(256), 0, ctx->stream, which, ctx->counters);
   TDT_HIP(ctx, hipGetLastError());

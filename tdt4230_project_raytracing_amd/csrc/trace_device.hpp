@@ -260,6 +260,10 @@ TDT_DEV bool tree_lookup(const TraceParams &P, const NodeSource &ns, float cx, f
 // key = node index (29 bits) | code << 30.
 template <int CL>
 struct NodeMemo { uint32_t key[CL]; uint32_t val[CL]; };
+// a pixel's cost for the hand-out order of the next dispatch (tdt_rt.hip, "Cost-feedback scheduling"):
+// tree levels visited + kCostStep per traversal step + kCostEvent per path event (measured plateau 24..128)
+constexpr uint32_t kCostStep = 3, kCostEvent = 64;
+constexpr uint32_t kEventWindow = 1024;   // rays after which the adaptive event threshold's running counts are halved
 constexpr int kMemoLevels = 9;
 constexpr int kMemoFirst = 3;       // levels 1..3 = cells 0..72 at most: always inside the LDS table
 

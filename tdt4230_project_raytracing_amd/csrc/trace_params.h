@@ -20,10 +20,11 @@ struct TraceParams {
   // output image (RGBA32F, row 0 = bottom) and optional per-pixel carry (16 floats / pixel)
   float *image;
   float *carry;
+  uint32_t *pixel_log;          // TDT_PIXEL_LOG diagnostics (8 u32 per queue slot), or null
   unsigned long long *counters; // instrumented launches only: event totals (see Counters)
   unsigned int *queue;          // global pixel queue head (zeroed before every launch)
-  const uint32_t *tile_order;   // owned work-group indices, most expensive first (from the previous dispatch), or null
-  uint32_t *tile_cost;          // per owned work-group: summed pixel times of THIS dispatch (feeds the next one), or null
+  const uint32_t *slot_order;   // queue slots (work-group * 1024 + pixel), most expensive first (from the previous dispatch), or null
+  uint32_t *slot_cost;          // per queue slot: pixel time of THIS dispatch (feeds the next one), or null
   const uint16_t *packed;       // cells [0, lds_cells) re-encoded as 16 bits per node: value << 2 | code
   uint32_t lds_nodes;           // number of nodes (8 per cell) staged in LDS by every block
   int32_t compact;             // 1: image is this rank's tile buffer [owned tile k][32][32] RGBA

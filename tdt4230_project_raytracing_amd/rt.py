@@ -61,6 +61,8 @@ SYMBOLS = [
     ("tdt_assemble_tiles", _I, [_P, _P, _I, _I, _P, _I, _I, _I]),
     ("tdt_dispatch_counted", _I, [_P, _I, _I, _I, ctypes.POINTER(ctypes.c_uint64)]),
     ("tdt_debug_counters", _I, [_P, ctypes.POINTER(ctypes.c_uint64)]),
+    ("tdt_debug_wave_ends", _I, [_P, ctypes.POINTER(ctypes.c_uint64), _I]),
+    ("tdt_debug_pixel_log", _I, [_P, ctypes.c_void_p, ctypes.c_size_t]),
     ("tdt_selftest", _I, [_P, _I, ctypes.POINTER(ctypes.c_uint64)]),
 ]
 
@@ -265,7 +267,20 @@ class ComputeShader:
     def debug_counters(self):
         c = (ctypes.c_uint64 * 32)()
         self.ctx.check(lib().tdt_debug_counters(self.ctx.h, c))
-        return dict(zip(self.DEBUG_FIELDS, [int(v) for v in c[8:18]]))
+        d = dict(zip(self.DEBUG_FIELDS, [int(v) for v in c[8:18]]))
+        d.update(first_start=int(c[18]), last_end=int(c[19]), sum_wave_cycles=int(c[20]), waves=int(c[21]), queue_empty=int(c[22]))
+        return d
+
+    def debug_wave_ends(self, n):
+        c = (ctypes.c_uint64 * n)()
+        self.ctx.check(lib().tdt_debug_wave_ends(self.ctx.h, c, n))
+        return np.array(c, dtype=np.uint64)
+
+    def debug_pixel_log(self, slots):
+        """(slots, 8) uint32 per-pixel log of the last dispatch_counted; needs TDT_PIXEL_LOG in the environment."""
+        log = np.zeros((slots, 8), np.uint32)
+        self.ctx.check(lib().tdt_debug_pixel_log(self.ctx.h, log.ctypes.data, log.size))
+        return log
 
     def dispatch_counted(self, width, height, depth=1):
         """Instrumented dispatch: event totals that define the algorithmic bytes."""

@@ -171,10 +171,12 @@ def test_unspecialised_kernel_equals_specialised(oracle, monkeypatch, cfg, W, H)
         r.close()
 
 
-def test_cost_feedback_order_changes_only_the_schedule(oracle, monkeypatch):
-    """From the second dispatch of a context on, work-groups of an LDS-resident scene are handed out most
-    expensive first (costs measured by the previous dispatch).  Every frame must still be the same bits."""
-    scene = host.Scene.config(2)
+@pytest.mark.parametrize("cfg", [2, 3])
+def test_cost_feedback_order_changes_only_the_schedule(oracle, monkeypatch, cfg):
+    """From the second dispatch of a context on, pixels are handed out most expensive first (work counts recorded
+    by the previous dispatch) — for the LDS-resident 64^3 tree and for the 256^3 one that lives in L2/HBM alike.
+    Every frame must still be the same bits."""
+    scene = host.Scene.config(cfg)
     cam = host.camera_reference_pose(320, 192, 3, 8)
     ref = oracle.render(scene, cam, threads=8)
     r = rt.Renderer(scene, cam)

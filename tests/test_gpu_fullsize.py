@@ -54,9 +54,11 @@ def test_oracle_on_sampled_bands(oracle, frame):
 def test_deterministic_and_specialisation_invariant(frame, monkeypatch):
     cfg, scene, cam, img = frame
     r = rt.Renderer(scene, cam)
-    again = r.render()
+    again = r.render()                  # image order (first dispatch of the context)
+    sorted1 = r.render()                # pixels in cost-feedback order
+    sorted2 = r.render()
     r.close()
-    assert digest(again) == digest(img)
+    assert digest(again) == digest(img) and digest(sorted1) == digest(img) and digest(sorted2) == digest(img)
     monkeypatch.setenv("TDT_NO_SPECIALISE", "1")
     r = rt.Renderer(scene, cam)
     plain = r.render()

@@ -7,7 +7,9 @@ cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 W, H, spp, b = (1920, 1080, 16, 8) if len(sys.argv) < 6 else map(int, sys.argv[2:6])
 scene = host.Scene.config(cfg); cam = host.camera_reference_pose(W, H, spp, b)
 r = rt.Renderer(scene, cam)
-c = r.shader.dispatch_counted(W + 1, H + 1, 1); d = r.shader.debug_counters(); r.close()
+for _ in range(int(os.environ.get("UTIL_DISPATCHES", "1"))):   # > 1: the later ones run in cost-feedback order
+    c = r.shader.dispatch_counted(W + 1, H + 1, 1); d = r.shader.debug_counters()
+r.close()
 print(json.dumps(c)); print(json.dumps(d))
 for k in ("trav", "level", "event", "scatter"):
     print(f"{k:8s} util {d[k+'_active']/max(1,d[k+'_slots']):.3f}  slots {d[k+'_slots']:.4g}")
