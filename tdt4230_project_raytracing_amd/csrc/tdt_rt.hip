@@ -109,12 +109,13 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   pc.root = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}; pc.leaf = pc.root; pc.root_t = 0.f;
   const int s_end = P.spp_begin + P.spp_count;
 
-  // adaptive event threshold (wave-uniform): the more traversal work a ray is, the less it pays to
-  // keep finished lanes waiting for company before running the event code.  Measured optima over
-  // the BASELINE scenes fit  threshold ~ K / (traversal steps per ray * max_depth),  K ~ 2400 (1600 before
-  // pixels were handed out in cost order).  The counts are a sliding window (kEventWindow rays): in cost order
-  // a wave meets the expensive pixels first and the sky last, and a threshold learnt on the former made the
-  // latter run the event code on every pass.
+  // adaptive event threshold (wave-uniform).  Model: a traversal pass costs C_t issue slots, an event pass C_e
+  // whatever the number of lanes it serves; with threshold T about T/2 lanes idle through the traversal
+  // passes, and rays of n steps arrive at the event code at a rate of (64 - T/2) / n per pass.  Rays served
+  // per issue slot peak at  T = 64 / (1/2 + sqrt(r n)),  r = C_t / (2 C_e);  n is measured per wave over a
+  // sliding window of kEventWindow rays (in cost order a wave meets the expensive pixels first and the sky
+  // last).  r (P.event_k) is fitted: 0.2 while the tree fits one XCD's L2, rising to 0.5 beyond — there the
+  // node loads' latency, not issue slots, bounds a traversal pass and event passes come almost free.
   uint32_t w_steps = 0, w_rays = 0, lane_work = 0;
   int threshold = P.event_threshold > 0 ? P.event_threshold : 24;
 
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     w_rays += (uint32_t)__popcll(__ballot(state == ST_NEWRAY));
     if (P.event_threshold <= 0) {
       if (w_rays > kEventWindow) { w_steps >>= 1; w_rays >>= 1; }   // sliding window: the mix of pixels a wave sees changes over a frame
-      const float est = P.event_k * (float)w_rays / ((float)w_steps * (float)P.max_depth + 1.0f);
+      const float est = 64.0f / (0.5f + __builtin_sqrtf(P.event_k * (float)w_steps / ((float)w_rays + 1.0f)));
       const int th = (int)est;
       threshold = w_rays < 256u ? 24 : (th < 2 ? 2 : (th > 40 ? 40 : th));
     }
@@ -464,34 +465,35 @@ __global__ __launch_bounds__(64) void octree_update_kernel(uint32_t *cells, uint
 // different number of work-groups, runs in image order.  Only the schedule changes: every pixel is computed
 // exactly as before.  Measured (MI355X, steady state): 1080p/64 spp 64^3 38.1 -> 34.5 ms, 4K/64 spp 256^3
 // 437 -> 369 ms, 1080p/64 spp 512^3 288 -> 201 ms.
-// Counting sort by a 256-bin logarithmic cost key (8 bins per octave), descending, in two passes over chunks
-// of kOrderChunk slots: order_hist_kernel sums per-chunk LDS histograms into hist[256]; order_scatter_kernel
+// Counting sort by a 512-bin logarithmic cost key (16 bins per octave), descending, in two passes over chunks
+// of kOrderChunk slots: order_hist_kernel sums per-chunk LDS histograms into hist[512]; order_scatter_kernel
 // reserves each chunk's range of every bin with one atomic on cursor[bin] and scatters through LDS counters.
-constexpr uint32_t kOrderChunk = 8192;
-__device__ __forceinline__ uint32_t order_key(uint32_t c) {   // larger cost -> smaller key; never-run slots last
-  if (c == 0) return 255u;
+constexpr uint32_t kOrderChunk = 8192, kOrderBits = 4;   // 2^kOrderBits bins per octave of cost (16: 512 bins)
+__device__ __forceinline__ uint32_t order_key(uint32_t c, uint32_t g) {   // larger cost -> smaller key; never-run slots last
+  const uint32_t last = (32u << g) - 1u;
+  if (c == 0) return last;
   const uint32_t e = 31u - (uint32_t)__builtin_clz(c);
-  const uint32_t frac = e >= 3 ? (c >> (e - 3)) & 7u : (c << (3 - e)) & 7u;
-  return 255u - (e * 8u + frac);
+  const uint32_t frac = e >= g ? (c >> (e - g)) & ((1u << g) - 1u) : (c << (g - e)) & ((1u << g) - 1u);
+  return last - ((e << g) + frac);
 }
-__global__ __launch_bounds__(1024) void order_hist_kernel(const uint32_t *__restrict__ cost, uint32_t n, uint32_t *__restrict__ hist) {
-  __shared__ uint32_t s_bin[256];
-  if (threadIdx.x < 256) s_bin[threadIdx.x] = 0;
+__global__ __launch_bounds__(1024) void order_hist_kernel(const uint32_t *__restrict__ cost, uint32_t n, uint32_t *__restrict__ hist, uint32_t g) {
+  __shared__ uint32_t s_bin[512];
+  if (threadIdx.x < 512) s_bin[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t lo = blockIdx.x * kOrderChunk, hi = lo + kOrderChunk < n ? lo + kOrderChunk : n;
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) atomicAdd(&s_bin[order_key(cost[i])], 1u);
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) atomicAdd(&s_bin[order_key(cost[i], g)], 1u);
   __syncthreads();
-  if (threadIdx.x < 256 && s_bin[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_bin[threadIdx.x]);
+  if (threadIdx.x < 512 && s_bin[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_bin[threadIdx.x]);
 }
 __global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restrict__ cost, uint32_t n, const uint32_t *__restrict__ hist,
-                                                             uint32_t *__restrict__ cursor, uint32_t *__restrict__ order) {
-  __shared__ uint32_t s_bin[256], s_base[256];
-  if (threadIdx.x < 256) s_bin[threadIdx.x] = 0;
+                                                             uint32_t *__restrict__ cursor, uint32_t *__restrict__ order, uint32_t g) {
+  __shared__ uint32_t s_bin[512], s_base[512];
+  if (threadIdx.x < 512) s_bin[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t lo = blockIdx.x * kOrderChunk, hi = lo + kOrderChunk < n ? lo + kOrderChunk : n;
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) atomicAdd(&s_bin[order_key(cost[i])], 1u);
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) atomicAdd(&s_bin[order_key(cost[i], g)], 1u);
   __syncthreads();
-  if (threadIdx.x < 256) {
+  if (threadIdx.x < 512) {
     uint32_t before = 0;
     for (uint32_t b = 0; b < threadIdx.x; b++) before += hist[b];
     const uint32_t mine = s_bin[threadIdx.x];
@@ -499,7 +501,7 @@ __global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restric
   }
   __syncthreads();
   for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) {
-    order[atomicAdd(&s_base[order_key(cost[i])], 1u)] = i;
+    order[atomicAdd(&s_base[order_key(cost[i], g)], 1u)] = i;
     cost[i] = 0;
   }
 }
@@ -561,7 +563,7 @@ struct tdt_ctx {
   int num_cus;
   bool force_generic;   // TDT_FORCE_GENERIC=1: always run the literal-arithmetic kernel (A/B testing)
   int event_threshold;  // TDT_EVENT_THRESHOLD=n fixes the event threshold (experiments); 0 = adaptive
-  float event_k;        // TDT_EVENT_K overrides the adaptive constant
+  float event_k;        // TDT_EVENT_K overrides the adaptive threshold's r (0: chosen from the tree size)
   uint32_t *pixel_log; size_t pixel_log_u32;   // TDT_PIXEL_LOG diagnostics (instrumented dispatches only)
   bool no_specialise;   // TDT_NO_SPECIALISE=1: never pick a scene-specialised kernel (A/B testing)
   std::vector<tdt_buffer *> buffers;
@@ -670,7 +672,11 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
                    "bound image is neither camera.image_width x image_height nor a 32 x 32*tiles tile buffer");
   P.spp_begin = spp_begin; P.spp_count = spp_count; P.mode = mode; P.total_spp = total_spp;
   P.event_threshold = ctx->event_threshold;   // 0: adaptive (see trace_kernel)
-  P.event_k = ctx->event_k;
+  {  // r of the adaptive event threshold (see trace_kernel): 0.2 up to 2 MiB of cells, 0.5 from 5 MiB on
+    const float mib = (float)ctx->ssbo[TDT_SLOT_CELLS]->bytes / 1048576.0f;
+    const float r = 0.1f * mib;
+    P.event_k = ctx->event_k > 0.0f ? ctx->event_k : (r < 0.2f ? 0.2f : (r > 0.5f ? 0.5f : r));
+  }
 
   TDT_HIP(ctx, hipSetDevice(ctx->device));
   if (ctx->ssbo[TDT_SLOT_CELLS]->bytes > 0xFFFFFFF8ull)
@@ -722,7 +728,7 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
         ctx->slot_cost = ctx->slot_order = nullptr; ctx->tile_capacity = 0; ctx->order_tiles = 0;
         TDT_HIP(ctx, hipMalloc((void **)&ctx->slot_cost, (size_t)t.owned * 1024 * sizeof(uint32_t)));
         TDT_HIP(ctx, hipMalloc((void **)&ctx->slot_order, (size_t)t.owned * 1024 * sizeof(uint32_t)));
-        if (!ctx->order_hist) TDT_HIP(ctx, hipMalloc((void **)&ctx->order_hist, 512 * sizeof(uint32_t)));
+        if (!ctx->order_hist) TDT_HIP(ctx, hipMalloc((void **)&ctx->order_hist, 1024 * sizeof(uint32_t)));
         ctx->tile_capacity = (uint32_t)t.owned;
       }
       if (ctx->order_tiles != (uint32_t)t.owned) {   // no usable history: image order, fresh cost array
@@ -770,10 +776,11 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     TDT_HIP(ctx, hipGetLastError());
     if (mode != 2 && P.slot_cost) {
       const uint32_t n_slots = (uint32_t)t.owned * 1024u, n_chunks = (n_slots + tdt::kOrderChunk - 1) / tdt::kOrderChunk;
-      TDT_HIP(ctx, hipMemsetAsync(ctx->order_hist, 0, 512 * sizeof(uint32_t), ctx->stream));
-      hipLaunchKernelGGL(tdt::order_hist_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, n_slots, ctx->order_hist);
+      const uint32_t og = tdt::kOrderBits;
+      TDT_HIP(ctx, hipMemsetAsync(ctx->order_hist, 0, 1024 * sizeof(uint32_t), ctx->stream));
+      hipLaunchKernelGGL(tdt::order_hist_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, n_slots, ctx->order_hist, og);
       hipLaunchKernelGGL(tdt::order_scatter_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, n_slots,
-                         ctx->order_hist, ctx->order_hist + 256, ctx->slot_order);
+                         ctx->order_hist, ctx->order_hist + 512, ctx->slot_order, og);
       TDT_HIP(ctx, hipGetLastError());
       ctx->order_tiles = (uint32_t)t.owned;
     }
@@ -810,7 +817,7 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
   { const char *fg = getenv("TDT_FORCE_GENERIC"); ctx->force_generic = fg && fg[0] == '1';
     const char *ns_ = getenv("TDT_NO_SPECIALISE"); ctx->no_specialise = ns_ && ns_[0] == '1';
     const char *et = getenv("TDT_EVENT_THRESHOLD"); ctx->event_threshold = et ? atoi(et) : 0;
-    const char *ek = getenv("TDT_EVENT_K"); ctx->event_k = ek ? (float)atof(ek) : 2400.0f; }
+    const char *ek = getenv("TDT_EVENT_K"); ctx->event_k = ek ? (float)atof(ek) : 0.0f; }
   if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
   else {
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);

@@ -36,5 +36,5 @@ struct TraceParams {
   int32_t mode;                // 0 render (sum, sqrt, clamp, store), 1 accumulate into image, 2 resolve
   int32_t total_spp;           // resolve divisor
   int32_t event_threshold;     // > 0: fixed number of lanes that must wait for the event code; 0: adaptive
-  float event_k;               // adaptive threshold constant
+  float event_k;               // adaptive threshold: r = C_t / (2 C_e) of the model in trace_kernel
 };
