@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc counter_collection.csv files for the trace kernel (per dispatch means)."""
+"""Summarise rocprofv3 --pmc counter_collection.csv files for the trace kernel: the LAST dispatch of the run (the
+steady state: the first dispatch of a context runs in image order, the later ones in cost-feedback order)."""
 import csv, glob, json, sys
 out = {}
 for d in sys.argv[1:]:
@@ -7,9 +8,10 @@ for d in sys.argv[1:]:
         acc = {}
         for r in csv.DictReader(open(f)):
             if "trace_kernel<0, false" in r["Kernel_Name"]:
-                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                acc.setdefault(r["Counter_Name"], []).append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
         for k, v in acc.items():
-            out[k] = sum(v) / len(v)
+            last = max(i for i, _ in v)
+            out[k] = sum(x for i, x in v if i == last)
 d = out
 def g(k): return d.get(k, float("nan"))
 print(json.dumps(out, indent=1))
