@@ -76,10 +76,12 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   __shared__ __attribute__((aligned(16))) uint16_t s_nodes[kLdsCells * 8 + 8];   // + the sentinel slot
   for (uint32_t i = threadIdx.x * 8u; i < P.lds_nodes; i += (uint32_t)TDT_BLOCK * 8u)      // one cell (8 x u16) per lane and trip
     *reinterpret_cast<uint4 *>(&s_nodes[i]) = *reinterpret_cast<const uint4 *>(&P.packed[i]);
-  if (threadIdx.x == 0) s_nodes[P.lds_nodes] = (uint16_t)((RESIDENT && POW2) ? 0u : kPackedEscape);
+  // sentinel: the rest of a partial last cell and one more cell (RESIDENT: all EMPTY, see tree_lookup_pow2), or the escape code
+  if (threadIdx.x < 16 && P.lds_nodes + threadIdx.x < ((P.lds_nodes + 7u) & ~7u) + 8u)
+    s_nodes[P.lds_nodes + threadIdx.x] = (uint16_t)((RESIDENT && POW2) ? 0u : kPackedEscape);
   __syncthreads();
   NodeSource ns;
-  ns.lds = s_nodes; ns.lds_nodes = P.lds_nodes;
+  ns.lds = s_nodes; ns.lds_nodes = P.lds_nodes; ns.lds_cells = (P.lds_nodes + 7u) >> 3;
   ns.cells = __builtin_amdgcn_make_buffer_rsrc((void *)P.cells, 0, (int)((P.cells_dwords >> 1) << 3), 0x00020000);
   const uint32_t total_slots = (uint32_t)P.owned_tiles * 1024u;
 

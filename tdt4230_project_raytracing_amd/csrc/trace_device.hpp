@@ -151,6 +151,7 @@ constexpr uint32_t kPackedMaxValue = 0x3FFEu;        // largest value an LDS ent
 struct NodeSource {
   const uint16_t *lds;                                // LDS table
   uint32_t lds_nodes;                                 // valid entries
+  uint32_t lds_cells;                                 // cells they make up (the last may be partial): index of the sentinel cell
   __amdgpu_buffer_rsrc_t cells;                       // raw buffer over the cells payload (8-byte granules)
 };
 
@@ -296,18 +297,40 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
   uint32_t Yi = (uint32_t)Yfl, Zi = (uint32_t)Zfl;
   Yi = (Yf == Yfl) ? (Yi & (Yi - 1u)) : Yi;
   Zi = (Zf == Zfl) ? (Zi & (Zi - 1u)) : Zi;
-  uint32_t qx = 0, v = 0, code = 1u;
-  int m = 0;                                          // levels visited
+  uint32_t qx = 1u, v = 0, code = 1u;                 // qx: x digits below a sentinel bit that counts the levels visited
   const float fx0 = fx;
   auto level = [&](int l, uint32_t *mkey, uint32_t *mval) {    // l = 1-based level
     const int sh = depth - l;
     const float fv = (float)v;
+    if (COUNT) { cnt.level_slots += slot64(); cnt.level_active++; cnt.node_loads++; }
+    if (RESIDENT && SAFEV) {
+      // Whole tree in the LDS table: the 8 children of cell v are 16 consecutive bytes, so one ds_read_b128 issued
+      // as soon as v is known overlaps the x decision below, and the child is then picked in registers.  Cells
+      // past the table read the all-EMPTY sentinel cell (a read past the end of the buffer IS 0: robust access).
+      const uint32_t cell = v < ns.lds_cells ? v : ns.lds_cells;
+      const uint4 c = *reinterpret_cast<const uint4 *>(ns.lds + (cell << 3));
+      const float q = (fv + fx) - fv;
+      const bool a = q > 0.5f, b = (q == 1.0f);
+      qx = qx + qx + ((a && !b) ? 1u : 0u);
+      const uint32_t yb = (Yi >> sh) & 1u, zb = (Zi >> sh) & 1u;
+      const uint32_t lo = a ? c.z : c.x, hi = a ? c.w : c.y;
+      uint32_t n = ((yb ? hi : lo) >> (zb << 4)) & 0xFFFFu;
+      if (__builtin_expect(__ballot(b) != 0ull, 0)) {    // q == 1: x index 2v + 2, the first half of the NEXT cell
+        if (b) {
+          const uint32_t idx = ((2u * v + 2u) << 2) + (yb << 1) + zb;
+          n = ns.lds[idx < ns.lds_nodes ? idx : ns.lds_nodes];
+        }
+      }
+      v = n >> 2; code = n & 3u;
+      fx = f_fract_nonneg(fx0 * __uint_as_float((uint32_t)(127 + l) << 23));
+      return;
+    }
     uint32_t ix; uint32_t bitx;
     if (SAFEV || __builtin_expect(__ballot(v >= (1u << 22)) == 0ull, 1)) {
       const float q = (fv + fx) - fv;
-      const uint32_t a = q > 0.5f ? 1u : 0u, b = (q == 1.0f) ? 1u : 0u;
-      ix = 2u * v + a + b;
-      bitx = a & ~b;
+      const bool a = q > 0.5f, b = (q == 1.0f);
+      ix = (v + v + (uint32_t)a) + (uint32_t)b;
+      bitx = (a && !b) ? 1u : 0u;
     } else {
       const float two_cc = (float)(int32_t)((uint32_t)P.cell_count << 1);
       const float rx = __builtin_rintf(((fv + fx) * P.inv_cell_count) * two_cc + -0.5f);
@@ -320,9 +343,8 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
         ix = 2u * v + a + b; bitx = a & ~b;
       }
     }
-    qx = (qx << 1) | bitx;
+    qx = qx + qx + bitx;
     const uint32_t idx = ((ix << 2) + (((Yi >> sh) & 1u) << 1) + ((Zi >> sh) & 1u)) & 0x1FFFFFFFu;
-    if (COUNT) { cnt.level_slots += slot64(); cnt.level_active++; cnt.node_loads++; }
     // LDS table first: an unconditional read of min(idx, lds_nodes).  The slot just past the table holds
     // a sentinel: EMPTY (0) when the whole buffer is resident — a read past the end of the buffer IS 0
     // (robust access) — and the escape code otherwise, which sends the lane to the range-checked HBM path.
@@ -342,7 +364,6 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
         if (mkey) { *mkey = idx | (code << 30); *mval = v; }
       }
     }
-    m = l;
     fx = f_fract_nonneg(fx0 * __uint_as_float((uint32_t)(127 + l) << 23));   // fract(c * 2^l): next level's coordinate
   };
 #pragma unroll
@@ -354,6 +375,8 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
     if (code == 1u && l <= depth) level(l, &memo.key[l - kMemoFirst - 1], &memo.val[l - kMemoFirst - 1]);
   }
   for (int l = kMemoFirst + CL + 1; code == 1u && l <= depth; l++) level(l, nullptr, nullptr);
+  const int m = 31 - __builtin_clz(qx);               // levels visited
+  qx ^= 1u << m;
   const float ipd = __uint_as_float((uint32_t)(127 - m) << 23);             // 2^-m = inv_pow_depth after m halvings
   inv_pow_depth = (m == 0) ? 1.0f : ipd;
   const int sh = depth - m;
