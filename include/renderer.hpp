@@ -127,6 +127,8 @@ class Texture {
     ctx_->check(tdt_image_read(img_, px.data()));
     return px;
   }
+  // NEW: the frame as the quad pass presents it (quad.frag:10), RGBA8, converted on the GPU
+  void read_rgba8(bool top_down, uint8_t *dst) const { ctx_->check(tdt_image_read_rgba8(img_, top_down ? 1 : 0, dst)); }
  private:
   Context *ctx_ = nullptr;
   tdt_image *img_ = nullptr;
@@ -226,21 +228,61 @@ class Octree {
 };
 
 // renderer/camera.rs:8-16
-struct CameraSettings { int32_t samples_per_pixel, max_bounce; float turn_rate, normal_speed, sprint_speed; };
+using CameraSettings = tdt_camera_settings;
+inline CameraSettings camera_settings_from_ron(const std::string &text) {                         // main.rs:171, 493
+  CameraSettings s;
+  if (tdt_camera_settings_from_ron(text.data(), text.size(), &s)) throw InitializeErr{InitializeErr::GL, 0x0501, "", "", tdt_host_last_error()};
+  return s;
+}
 
-// renderer/camera.rs:20-101 (orientation is the identity: quaternion yaw/pitch and the controller are next row §8f-3)
+// utility/mod.rs:6-26
+enum class Direction { Front, Back, Rigth, Left, Up, Down };
+inline Vector3f into_vector3(Direction d) {
+  switch (d) {
+    case Direction::Front: return {0.0f, 0.0f, -1.0f};
+    case Direction::Back: return {0.0f, 0.0f, 1.0f};
+    case Direction::Rigth: return {1.0f, 0.0f, 0.0f};
+    case Direction::Left: return {-1.0f, 0.0f, 0.0f};
+    case Direction::Up: return {0.0f, 1.0f, 0.0f};
+    default: return {0.0f, -1.0f, 0.0f};
+  }
+}
+
+// renderer/camera.rs:20-102: the controller state lives in libtdthost's tdt_camera (cgmath restated there)
 class Camera {
  public:
-  Vector3f horizontal{}, vertical{}, lower_left_corner{}, origin{};
-  float viewport_width = 0, viewport_height = 0;
-  int32_t image_width = 0, image_height = 0;
+  tdt_camera state{};
   Texture render_texture;
-  CameraSettings settings{};
-  void apply_settings(const Program &program, const CameraSettings &s) {                        // :96-101
-    settings = s;
-    program.set_i32("camera.samples_per_pixel", settings.samples_per_pixel);
-    program.set_i32("camera.max_bounce", settings.max_bounce);
+  const float *horizontal() const { return state.horizontal; }
+  const float *vertical() const { return state.vertical; }
+  const float *lower_left_corner() const { return state.lower_left_corner; }
+  const float *origin() const { return state.origin; }
+  int32_t image_width() const { return state.image_width; }
+  int32_t image_height() const { return state.image_height; }
+  const CameraSettings &settings() const { return state.settings; }
+  void translate(const Program &program, const Vector3f &by, double deltatime) {                   // :40-43
+    tdt_camera_translate(&state, by.data(), deltatime); propagate_changes(program);
   }
+  void turn_pitch(const Program &program, float angle) { tdt_camera_turn_pitch(&state, angle); propagate_changes(program); }   // :46-53
+  void turn_yaw(const Program &program, float angle) { tdt_camera_turn_yaw(&state, angle); propagate_changes(program); }       // :56-62
+  void set_speed_to_normal() { tdt_camera_set_speed_to_normal(&state); }                             // :84-86
+  void set_speed_to_sprint() { tdt_camera_set_speed_to_sprint(&state); }                             // :88-90
+  Vector3f look_at_world_point(float distance) const {                                              // :92-94
+    Vector3f p{}; tdt_camera_look_at_world_point(&state, distance, p.data()); return p;
+  }
+  void apply_settings(const Program &program, const CameraSettings &s) {                            // :96-101
+    tdt_camera_apply_settings(&state, &s);
+    program.set_i32("camera.samples_per_pixel", state.settings.samples_per_pixel);
+    program.set_i32("camera.max_bounce", state.settings.max_bounce);
+  }
+ private:
+  void propagate_changes(const Program &program) const {                                            // the uploads of :78-81
+    program.set_vector3_f32("camera.horizontal", {state.horizontal[0], state.horizontal[1], state.horizontal[2]});
+    program.set_vector3_f32("camera.vertical", {state.vertical[0], state.vertical[1], state.vertical[2]});
+    program.set_vector3_f32("camera.lower_left_corner", {state.lower_left_corner[0], state.lower_left_corner[1], state.lower_left_corner[2]});
+    program.set_vector3_f32("camera.origin", {state.origin[0], state.origin[1], state.origin[2]});
+  }
+  friend class CameraBuilder;
 };
 
 // renderer/camera.rs:104-237
@@ -257,34 +299,31 @@ class CameraBuilder {
   CameraBuilder &with_origin(const Vector3f &o) { b_.has_origin = 1; b_.origin[0] = o[0]; b_.origin[1] = o[1]; b_.origin[2] = o[2]; return *this; }
   CameraBuilder &with_sample_per_pixel(int32_t n) { b_.has_samples_per_pixel = 1; b_.samples_per_pixel = n; return *this; }
   CameraBuilder &with_max_bounce(int32_t n) { b_.has_max_bounce = 1; b_.max_bounce = n; return *this; }
-  CameraBuilder &with_turn_rate(float v) { turn_rate_ = v; return *this; }
-  CameraBuilder &with_normal_speed(float v) { normal_speed_ = v; has_normal_ = true; return *this; }
-  CameraBuilder &with_sprint_speed(float v) { sprint_speed_ = v; has_sprint_ = true; return *this; }
+  CameraBuilder &with_turn_rate(float v) { b_.has_turn_rate = 1; b_.turn_rate = v; return *this; }
+  CameraBuilder &with_normal_speed(float v) { b_.has_normal_speed = 1; b_.normal_speed = v; return *this; }
+  CameraBuilder &with_sprint_speed(float v) { b_.has_sprint_speed = 1; b_.sprint_speed = v; return *this; }
   Camera build(Context &ctx, const Program &program) const {                                     // :135-196
-    tdt_camera_uniforms u;
-    if (tdt_camera_build(&b_, &u)) throw InitializeErr{InitializeErr::GL, 0x0501, "", "", tdt_host_last_error()};
     Camera c;
-    for (int i = 0; i < 3; i++) { c.horizontal[i] = u.horizontal[i]; c.vertical[i] = u.vertical[i]; c.lower_left_corner[i] = u.lower_left_corner[i]; c.origin[i] = u.origin[i]; }
-    c.viewport_width = u.horizontal[0]; c.viewport_height = u.vertical[1];
-    c.image_width = u.image_width; c.image_height = u.image_height;
-    c.render_texture = Texture::new_2d(ctx, c.image_width, c.image_height);                      // :158-165
-    const float normal = has_normal_ ? normal_speed_ : 1.0f;
-    c.settings = {u.samples_per_pixel, u.max_bounce, turn_rate_, normal, has_sprint_ ? sprint_speed_ : normal * 2.0f};   // :167-169
+    if (tdt_camera_init(&b_, &c.state)) throw InitializeErr{InitializeErr::GL, 0x0501, "", "", tdt_host_last_error()};
+    c.render_texture = Texture::new_2d(ctx, c.state.image_width, c.state.image_height);          // :158-165
     // initial_uniforms, camera.rs:241-253
-    program.set_i32("camera.image_width", c.image_width);
-    program.set_i32("camera.image_height", c.image_height);
-    program.set_vector3_f32("camera.horizontal", c.horizontal);
-    program.set_vector3_f32("camera.vertical", c.vertical);
-    program.set_vector3_f32("camera.lower_left_corner", c.lower_left_corner);
-    program.set_vector3_f32("camera.origin", c.origin);
-    program.set_i32("camera.samples_per_pixel", c.settings.samples_per_pixel);
-    program.set_i32("camera.max_bounce", c.settings.max_bounce);
+    program.set_i32("camera.image_width", c.state.image_width);
+    program.set_i32("camera.image_height", c.state.image_height);
+    c.propagate_changes(program);
+    program.set_i32("camera.samples_per_pixel", c.state.settings.samples_per_pixel);
+    program.set_i32("camera.max_bounce", c.state.settings.max_bounce);
     return c;
   }
  private:
   tdt_camera_builder b_;
-  float turn_rate_ = 0.025f, normal_speed_ = 1.0f, sprint_speed_ = 2.0f;
-  bool has_normal_ = false, has_sprint_ = false;
 };
+
+// Presentation: the frame the reference's quad pass would show (main.rs:582-600, quad.frag:10), as a PNG file
+inline void present_png(Texture &texture, const std::string &path, bool with_alpha = false) {
+  std::vector<uint8_t> frame(static_cast<size_t>(texture.width()) * texture.height() * 4);
+  texture.read_rgba8(true, frame.data());
+  if (tdt_png_write(path.c_str(), frame.data(), texture.width(), texture.height(), with_alpha ? 1 : 0))
+    throw InitializeErr{InitializeErr::GL, 0x0501, "", "", tdt_host_last_error()};
+}
 
 }  // namespace renderer

@@ -31,6 +31,10 @@ typedef struct {
   int32_t has_origin;          float origin[3];         /* default 0     camera.rs:143 */
   int32_t has_samples_per_pixel; int32_t samples_per_pixel; /* default 10 camera.rs:156 */
   int32_t has_max_bounce;      int32_t max_bounce;      /* default 3     camera.rs:157 */
+  /* controller settings (only tdt_camera_init reads them; tdt_camera_build ignores them like build() does for the uniforms) */
+  int32_t has_turn_rate;       float turn_rate;         /* default 0.025 camera.rs:167 */
+  int32_t has_normal_speed;    float normal_speed;      /* default 1.0   camera.rs:168 */
+  int32_t has_sprint_speed;    float sprint_speed;      /* default 2 * normal_speed camera.rs:169 */
 } tdt_camera_builder;
 
 /* what initial_uniforms() sends (camera.rs:241-253) = `uniform Camera camera` raytracer.comp:133-146 */
@@ -44,6 +48,51 @@ int tdt_camera_build(const tdt_camera_builder *b, tdt_camera_uniforms *out);
 /* the pose main.rs:165-168 builds: fov 90, origin (0,-0.1,-0.3), viewport_height 2.0,
  * aspect = width/height (f32 division) */
 int tdt_camera_reference_pose(int width, int height, int spp, int max_bounce, tdt_camera_uniforms *out);
+
+/* ---- next row SURVEY §8f-3: the camera controller and its settings (camera.rs:8-16, 20-102) ----
+ * The reference's vector / quaternion arithmetic is the cgmath crate's (Cargo.lock: cgmath 0.18.0; not vendored, no Rust
+ * toolchain here): csrc/host_view.cpp restates its published formulas in f32.  PARITY UNPINNED (no reference fixture
+ * covers these values). */
+typedef struct {                 /* CameraSettings camera.rs:9-16 = assets/settings/camera.ron */
+  int32_t samples_per_pixel, max_bounce;
+  float turn_rate, normal_speed, sprint_speed;
+} tdt_camera_settings;
+
+typedef struct {                 /* Camera camera.rs:20-37, minus the GL texture */
+  float horizontal[3], vertical[3];
+  float viewport_width, viewport_height;
+  float lower_left_corner[3], origin[3];
+  float pitch[4], yaw[4];        /* quaternions in Quaternion::new(w, xi, yj, zk) order */
+  int32_t image_width, image_height;
+  tdt_camera_settings settings;
+  float movement_speed;
+} tdt_camera;
+
+int tdt_camera_init(const tdt_camera_builder *b, tdt_camera *cam);                     /* CameraBuilder::build camera.rs:135-196 */
+int tdt_camera_translate(tdt_camera *cam, const float by[3], double deltatime);        /* camera.rs:40-43; `by` e.g. Direction::into_vector3 utility/mod.rs:15-26 */
+int tdt_camera_turn_pitch(tdt_camera *cam, float angle);                               /* camera.rs:46-53 */
+int tdt_camera_turn_yaw(tdt_camera *cam, float angle);                                 /* camera.rs:56-62 */
+void tdt_camera_set_speed_to_normal(tdt_camera *cam);                                  /* camera.rs:84-86 */
+void tdt_camera_set_speed_to_sprint(tdt_camera *cam);                                  /* camera.rs:88-90 */
+int tdt_camera_look_at_world_point(const tdt_camera *cam, float distance, float out[3]);   /* camera.rs:92-94 (main.rs:555) */
+int tdt_camera_apply_settings(tdt_camera *cam, const tdt_camera_settings *s);          /* camera.rs:96-101 */
+/* the uniforms propagate_changes / apply_settings / initial_uniforms have sent so far (camera.rs:78-81, 99-100, 241-253) */
+int tdt_camera_get_uniforms(const tdt_camera *cam, tdt_camera_uniforms *out);
+/* `ron::de::from_bytes::<CameraSettings>` (main.rs:171, 493) for the RON subset such a file uses: optional struct name,
+ * `field: number` pairs in any order, comments, optional trailing comma; a missing field or a float where an i32 is
+ * expected is an error (returns 1, message in tdt_host_last_error) */
+int tdt_camera_settings_from_ron(const char *text, size_t n, tdt_camera_settings *out);
+
+/* ---- next row SURVEY §8f-4: presentation ----
+ * The reference shows the render texture with a full-window quad (assets/shaders/quad.vert, quad.frag:10; main.rs:113-153,
+ * 582-600) and never writes a file.  tdt_present_rgba8 is what that pass leaves in an RGBA8 back buffer of the texture's
+ * size (pinned on llvmpipe: tests/golden/present_*.npz): per channel clamp to [0,1] (NaN -> 0), x 255, round half to even.
+ * Source rows are bottom-up (row 0 = bottom scan-line); top_down = 1 writes the top scan-line first (file order). */
+int tdt_present_rgba8(const float *rgba, int w, int h, int top_down, uint8_t *dst);
+/* 8-bit PNG (colour type 2, or 6 with_alpha) of a TOP-DOWN RGBA8 frame; *out is malloc'ed: release with tdt_host_free */
+int tdt_png_encode(const uint8_t *rgba8, int w, int h, int with_alpha, uint8_t **out, size_t *len);
+int tdt_png_write(const char *path, const uint8_t *rgba8, int w, int h, int with_alpha);
+void tdt_host_free(void *p);
 
 /* ---------------------------------------------------------------- scenes ---------------- */
 typedef struct tdt_scene tdt_scene;

@@ -123,6 +123,11 @@ void *tdt_image_device_ptr(const tdt_image *img);
 /* NEW (the reference never reads back; quad.frag samples the texture): finishes the stream and
  * copies W*H*4 floats to dst */
 int tdt_image_read(tdt_image *img, float *dst);
+/* NEXT ROW SURVEY §8f-4, presentation: the RGBA8 frame the reference's quad pass (assets/shaders/quad.frag:10,
+ * main.rs:582-600) leaves in a back buffer of the texture's size — per channel clamp to [0,1] (NaN -> 0), x 255, round half
+ * to even (pinned on llvmpipe) — converted on the GPU, then W*H*4 bytes copied to dst after finishing the stream.
+ * Texture row 0 is the bottom scan-line; top_down = 1 writes the top scan-line first (image-file order). */
+int tdt_image_read_rgba8(tdt_image *img, int top_down, uint8_t *dst);
 
 /* ---- dispatch --------------------------------------------------------------------------- */
 /* ComputeShader::dispatch_compute(width, height, depth) (compute_shader.rs:28-38; called with

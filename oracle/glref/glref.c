@@ -15,6 +15,8 @@
  *   Texture::new_2d RGBA32F + BindImageTexture     (src/renderer/texture.rs:47-75)
  *   Program::set_i32 / set_vector3_f32             (src/renderer/program.rs:35-83)
  *   ComputeShader::dispatch_compute                (src/renderer/compute_shader.rs:28-38)
+ *   the presentation pass: quad program, vertex/index buffers, draw (src/main.rs:113-153, 582-600)
+ *     — into an RGBA8 framebuffer object instead of a window's back buffer (there is no window)
  *
  * Nothing of the reference is copied here: the shader text is read from $REF_DIR when
  * glref_program() is called.  Build products go to oracle/_ref/ (git-ignored).
@@ -70,7 +72,24 @@ static glproc_t (*glapi_get_proc)(const char *);
   X(PFNGLMEMORYBARRIERPROC, glMemoryBarrier) \
   X(PFNGLFINISHPROC, glFinish) \
   X(PFNGLGETPROGRAMRESOURCEINDEXPROC, glGetProgramResourceIndex) \
-  X(PFNGLGETPROGRAMRESOURCEIVPROC, glGetProgramResourceiv)
+  X(PFNGLGETPROGRAMRESOURCEIVPROC, glGetProgramResourceiv) \
+  X(PFNGLTEXSUBIMAGE2DPROC, glTexSubImage2D) \
+  X(PFNGLGENVERTEXARRAYSPROC, glGenVertexArrays) \
+  X(PFNGLDELETEVERTEXARRAYSPROC, glDeleteVertexArrays) \
+  X(PFNGLBINDVERTEXARRAYPROC, glBindVertexArray) \
+  X(PFNGLVERTEXATTRIBPOINTERPROC, glVertexAttribPointer) \
+  X(PFNGLENABLEVERTEXATTRIBARRAYPROC, glEnableVertexAttribArray) \
+  X(PFNGLGENFRAMEBUFFERSPROC, glGenFramebuffers) \
+  X(PFNGLDELETEFRAMEBUFFERSPROC, glDeleteFramebuffers) \
+  X(PFNGLBINDFRAMEBUFFERPROC, glBindFramebuffer) \
+  X(PFNGLFRAMEBUFFERTEXTURE2DPROC, glFramebufferTexture2D) \
+  X(PFNGLCHECKFRAMEBUFFERSTATUSPROC, glCheckFramebufferStatus) \
+  X(PFNGLVIEWPORTPROC, glViewport) \
+  X(PFNGLCLEARCOLORPROC, glClearColor) \
+  X(PFNGLCLEARPROC, glClear) \
+  X(PFNGLDRAWELEMENTSPROC, glDrawElements) \
+  X(PFNGLREADPIXELSPROC, glReadPixels) \
+  X(PFNGLPIXELSTOREIPROC, glPixelStorei)
 
 #define X(T, N) static T p_##N;
 GLFUNCS(X)
@@ -307,4 +326,91 @@ int glref_buffer_variable(const char *name, int out_offset_stride[2]) {
   p_glGetProgramResourceiv(g_prog, GL_BUFFER_VARIABLE, idx, 2, props, 2, NULL, vals);
   out_offset_stride[0] = vals[0]; out_offset_stride[1] = vals[1];
   return 0;
+}
+
+/* Overwrites the render texture with caller data (W*H*4 floats, row 0 = bottom) — for presentation tests on
+ * crafted values. */
+int glref_image_write(const float *src) {
+  p_glBindTexture(GL_TEXTURE_2D, g_tex);
+  p_glTexSubImage2D(GL_TEXTURE_2D, 0, 0, 0, g_tex_w, g_tex_h, GL_RGBA, GL_FLOAT, src);
+  return (int)p_glGetError();
+}
+
+static GLuint load_stage(GLenum kind, const char *path) {
+  FILE *f = fopen(path, "rb");
+  if (!f) { snprintf(g_err, sizeof g_err, "cannot open shader %s", path); return 0; }
+  fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+  char *src = (char *)malloc((size_t)n + 1);
+  if (fread(src, 1, (size_t)n, f) != (size_t)n) { fclose(f); free(src); snprintf(g_err, sizeof g_err, "short read"); return 0; }
+  src[n] = 0; fclose(f);
+  GLuint sh = p_glCreateShader(kind);
+  const GLchar *srcs[1] = { src };
+  p_glShaderSource(sh, 1, srcs, NULL);
+  p_glCompileShader(sh);
+  free(src);
+  GLint ok = 0;
+  p_glGetShaderiv(sh, GL_COMPILE_STATUS, &ok);
+  if (!ok) { p_glGetShaderInfoLog(sh, sizeof g_err, NULL, g_err); return 0; }
+  return sh;
+}
+
+/* The reference's presentation pass (main.rs:113-153 set-up, 582-600 per frame): Program::from_resources(
+ * "shaders/quad") = quad.vert + quad.frag, the 4-vertex / 6-index quad, Clear, DrawElements — drawn into an
+ * RGBA8 colour attachment of vw x vh pixels (the window's back buffer in the reference; glViewport(0,0,vw,vh),
+ * main.rs:114), then read back with glReadPixels: out = vh*vw*4 bytes, row 0 = bottom. */
+int glref_present(const char *vert_path, const char *frag_path, int vw, int vh, unsigned char *out) {
+  if (!g_ready || !g_tex) { snprintf(g_err, sizeof g_err, "no context / render texture"); return -1; }
+  GLuint vs = load_stage(GL_VERTEX_SHADER, vert_path); if (!vs) return -2;
+  GLuint fs = load_stage(GL_FRAGMENT_SHADER, frag_path); if (!fs) return -2;
+  GLuint prog = p_glCreateProgram();
+  p_glAttachShader(prog, vs); p_glAttachShader(prog, fs);
+  p_glLinkProgram(prog);
+  GLint ok = 0;
+  p_glGetProgramiv(prog, GL_LINK_STATUS, &ok);
+  if (!ok) { p_glGetProgramInfoLog(prog, sizeof g_err, NULL, g_err); return -3; }
+  p_glDeleteShader(vs); p_glDeleteShader(fs);
+  static const GLuint indices[6] = { 0, 1, 2, 0, 1, 3 };                                   /* main.rs:121-124 */
+  static const GLfloat vertices[20] = { -1.f, -1.f, 0.f, 0.f, 0.f,   1.f, 1.f, 0.f, 1.f, 1.f,   /* main.rs:141-146 */
+                                        -1.f, 1.f, 0.f, 0.f, 1.f,    1.f, -1.f, 0.f, 1.f, 0.f };
+  GLuint vao = 0, vbo = 0, ebo = 0, fbo = 0, color = 0;
+  p_glGenVertexArrays(1, &vao); p_glBindVertexArray(vao);
+  p_glGenBuffers(1, &vbo); p_glBindBuffer(GL_ARRAY_BUFFER, vbo);
+  p_glBufferData(GL_ARRAY_BUFFER, sizeof vertices, vertices, GL_STATIC_DRAW);
+  p_glVertexAttribPointer(0, 3, GL_FLOAT, GL_FALSE, 5 * sizeof(GLfloat), (const void *)0);                       /* vao.rs:45-58 */
+  p_glEnableVertexAttribArray(0);
+  p_glVertexAttribPointer(1, 2, GL_FLOAT, GL_FALSE, 5 * sizeof(GLfloat), (const void *)(3 * sizeof(GLfloat)));
+  p_glEnableVertexAttribArray(1);
+  p_glGenBuffers(1, &ebo); p_glBindBuffer(GL_ELEMENT_ARRAY_BUFFER, ebo);
+  p_glBufferData(GL_ELEMENT_ARRAY_BUFFER, sizeof indices, indices, GL_STATIC_DRAW);
+  p_glGenTextures(1, &color);
+  p_glActiveTexture(GL_TEXTURE1);
+  p_glBindTexture(GL_TEXTURE_2D, color);
+  p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_NEAREST);
+  p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_NEAREST);
+  p_glTexImage2D(GL_TEXTURE_2D, 0, GL_RGBA8, vw, vh, 0, GL_RGBA, GL_UNSIGNED_BYTE, NULL);
+  p_glGenFramebuffers(1, &fbo); p_glBindFramebuffer(GL_FRAMEBUFFER, fbo);
+  p_glFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, color, 0);
+  int rc = 0;
+  if (p_glCheckFramebufferStatus(GL_FRAMEBUFFER) != GL_FRAMEBUFFER_COMPLETE) { snprintf(g_err, sizeof g_err, "framebuffer incomplete"); rc = -4; }
+  if (!rc) {
+    p_glActiveTexture(GL_TEXTURE0);                      /* the render texture stays bound to unit 0 (texture.rs:55-56); */
+    p_glBindTexture(GL_TEXTURE_2D, g_tex);               /* `ourTexture` is never set, i.e. unit 0 (quad.frag:6) */
+    p_glViewport(0, 0, vw, vh);
+    p_glClearColor(0.f, 0.f, 0.f, 1.f);                  /* main.rs:115 */
+    p_glUseProgram(prog);
+    p_glClear(GL_COLOR_BUFFER_BIT);
+    p_glDrawElements(GL_TRIANGLES, 6, GL_UNSIGNED_INT, (const void *)0);
+    p_glUseProgram(0);
+    p_glFinish();
+    p_glPixelStorei(GL_PACK_ALIGNMENT, 1);
+    p_glReadPixels(0, 0, vw, vh, GL_RGBA, GL_UNSIGNED_BYTE, out);
+    if (p_glGetError() != GL_NO_ERROR) { snprintf(g_err, sizeof g_err, "GL error in the presentation pass"); rc = -5; }
+  }
+  p_glBindFramebuffer(GL_FRAMEBUFFER, 0);
+  p_glBindVertexArray(0);
+  p_glDeleteFramebuffers(1, &fbo); p_glDeleteTextures(1, &color);
+  p_glDeleteBuffers(1, &vbo); p_glDeleteBuffers(1, &ebo); p_glDeleteVertexArrays(1, &vao);
+  p_glDeleteProgram(prog);
+  p_glActiveTexture(GL_TEXTURE0);
+  return rc;
 }

@@ -150,7 +150,43 @@ def edits():
         print(f"{name}: {changed.size} dwords changed, counter {counter} -> {cnt}")
 
 
+def present_input():
+    """The float frame of the presentation fixtures: every value class the UNORM8 conversion distinguishes."""
+    rng = np.random.default_rng(0x8F4)
+    W, H = 96, 40
+    img = rng.random((H, W, 4)).astype(np.float32)
+    img[1] = rng.uniform(-0.5, 1.5, (W, 4)).astype(np.float32)                       # out-of-range values
+    k = np.arange(W * 4, dtype=np.float32).reshape(W, 4)
+    img[2] = ((k % 255) + 0.5) / 255                                                 # ties (x*255 = k + 1/2, up to rounding)
+    img[3] = np.nextafter(img[2], np.float32(2), dtype=np.float32)                   # just above / below the ties
+    img[4] = np.nextafter(img[2], np.float32(-1), dtype=np.float32)
+    img[5] = (k % 256) / 255                                                         # exact codes
+    special = np.array([0.0, -0.0, 1.0, np.nan, np.inf, -np.inf, 1e-30, -1e-30, 0.999999, 1.000001, 0.5, 0.25], np.float32)
+    img[6, :len(special), 0] = special
+    img[6, :len(special), 3] = special[::-1]
+    return img
+
+
+def present():
+    """quad.vert + quad.frag run by llvmpipe into an RGBA8 colour buffer: bytes for crafted values and for a
+    rendered frame of the demo scene (1280x720 window scaled down to 160x96: 3 work-group rows, all written)."""
+    img = present_input()
+    out = oracle_py.glref_present(img)
+    np.savez_compressed(os.path.join(OUT, "present_values.npz"), image=img.view(np.uint32), rgba8=out,
+                        meta=json.dumps({"rows": "image and rgba8: row 0 = bottom scan-line (glReadPixels order)"}))
+    gl = oracle_py.GLRef.get()
+    scene = make_scene(("config", 0))
+    cam = host.camera_reference_pose(160, 100, 4, 6)
+    frame = gl.render(scene, cam)
+    out2 = oracle_py.glref_present(frame)
+    np.savez_compressed(os.path.join(OUT, "present_demo.npz"), image=frame.view(np.uint32), rgba8=out2,
+                        meta=json.dumps({"scene": ["config", 0], "camera": [160, 100, 4, 6],
+                                         "note": "rows 96..99 are never written by the floor-div dispatch: texture zeros -> 0,0,0,0"}))
+    print("present:", out.shape, out2.shape, "distinct bytes", len(np.unique(out2)))
+
+
 if __name__ == "__main__":
     main()
     math_table()
     edits()
+    present()

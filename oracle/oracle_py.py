@@ -149,6 +149,8 @@ class GLRef:
         L.glref_dispatch_compute.argtypes = [ctypes.c_int] * 3
         L.glref_dispatch_compute.restype = ctypes.c_double
         L.glref_buffer_variable.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+        L.glref_image_write.argtypes = [ctypes.c_void_p]
+        L.glref_present.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         if L.glref_init() != 0:
             raise RuntimeError(L.glref_last_error().decode())
         self.L = L
@@ -207,6 +209,24 @@ class GLRef:
         img = np.zeros((H, W, 4), np.float32)
         self.L.glref_image_read(img.ctypes.data)
         return (img, t) if want_time else img
+
+
+def glref_present(image, viewport=None):
+    """The reference's presentation pass (quad.vert + quad.frag, main.rs:113-153, 582-600) on llvmpipe for a W x H
+    RGBA32F render texture (row 0 = bottom): the RGBA8 frame a window of `viewport` = (w, h) pixels would hold,
+    as glReadPixels returns it (row 0 = bottom)."""
+    g = GLRef.get()
+    image = np.ascontiguousarray(image, np.float32)
+    H, W = image.shape[:2]
+    vw, vh = viewport if viewport else (W, H)
+    g.L.glref_image(W, H)
+    assert g.L.glref_image_write(image.ctypes.data) == 0
+    out = np.zeros((vh, vw, 4), np.uint8)
+    rc = g.L.glref_present(os.path.join(REF_DIR, "assets", "shaders", "quad.vert").encode(),
+                           os.path.join(REF_DIR, "assets", "shaders", "quad.frag").encode(), vw, vh, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"glref_present: {g.L.glref_last_error().decode()}")
+    return out
 
 
 def glref_math_table(xs):

@@ -36,9 +36,10 @@ def _run(cmd):
 
 def build_host(force=False):
     out = os.path.join(_HERE, "libtdthost.so")
-    srcs = [os.path.join(CSRC, "host_scene.cpp"), os.path.join(INCLUDE, "tdt_host.h"), os.path.abspath(__file__)]
+    srcs = [os.path.join(CSRC, "host_scene.cpp"), os.path.join(CSRC, "host_view.cpp"), os.path.join(INCLUDE, "tdt_host.h"),
+            os.path.abspath(__file__)]
     if force or _newer(out, srcs):
-        _run(["g++"] + HOST_FLAGS + ["-I", INCLUDE, srcs[0], "-o", out])
+        _run(["g++"] + HOST_FLAGS + ["-I", INCLUDE, srcs[0], srcs[1], "-o", out, "-lz"])      # zlib: the PNG writer (§8f-4)
     return out
 
 

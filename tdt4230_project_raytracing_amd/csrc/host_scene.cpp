@@ -408,6 +408,7 @@ bool ply_parse_strict(const uint8_t *buf, size_t n, tdt_ply &out) {
 extern "C" {
 
 const char *tdt_host_last_error(void) { return g_err.c_str(); }
+void tdt_host_set_error(const char *msg) { g_err = msg ? msg : ""; }   // for host_view.cpp
 
 int tdt_camera_build(const tdt_camera_builder *b, tdt_camera_uniforms *out) {
   if (!b || !out) { g_err = "null argument"; return 1; }

@@ -508,6 +508,21 @@ __global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restric
   }
 }
 
+// Presentation: the RGBA8 frame the reference's quad pass (quad.frag:10, main.rs:582-600) leaves in a back
+// buffer of the texture's size — clamp to [0,1] (NaN -> 0), x 255, round half to even (pinned on llvmpipe,
+// tests/golden/present_*.npz) — so that a frame leaves the GPU as 4 instead of 16 bytes per pixel.  HBM-streaming.
+__global__ __launch_bounds__(256) void present_kernel(const float4 *__restrict__ image, uint32_t *__restrict__ out, int w, int h, int top_down) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  const float4 c = image[(size_t)y * w + x];
+  auto u8 = [](float v) -> uint32_t {
+    const float t = !(v > 0.0f) ? 0.0f : (v > 1.0f ? 1.0f : v);
+    return (uint32_t)__builtin_rintf(t * 255.0f);
+  };
+  out[(size_t)(top_down ? h - 1 - y : y) * w + x] = u8(c.x) | (u8(c.y) << 8) | (u8(c.z) << 16) | (u8(c.w) << 24);
+}
+
 // De-interleave gathered per-rank tile buffers ([rank][k][32][32] RGBA) into a W x H image.
 __global__ __launch_bounds__(256) void assemble_kernel(const float4 *__restrict__ tiles, float4 *__restrict__ image,
                                                        int image_width, int cover_w, int cover_h, int tiles_x,
@@ -566,6 +581,7 @@ struct tdt_ctx {
   bool force_generic;   // TDT_FORCE_GENERIC=1: always run the literal-arithmetic kernel (A/B testing)
   int event_threshold;  // TDT_EVENT_THRESHOLD=n fixes the event threshold (experiments); 0 = adaptive
   float event_k;        // TDT_EVENT_K overrides the adaptive threshold's r (0: chosen from the tree size)
+  uint32_t *present; size_t present_bytes;   // staging of tdt_image_read_rgba8
   uint32_t *pixel_log; size_t pixel_log_u32;   // TDT_PIXEL_LOG diagnostics (instrumented dispatches only)
   bool no_specialise;   // TDT_NO_SPECIALISE=1: never pick a scene-specialised kernel (A/B testing)
   std::vector<tdt_buffer *> buffers;
@@ -812,7 +828,7 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
   if (!ctx) return fail(nullptr, TDT_ERR_HIP, "out of host memory");
   ctx->device = device_id;
   for (auto &s : ctx->ssbo) s = nullptr;
-  ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr; ctx->queue = nullptr; ctx->packed = nullptr; ctx->packed_of = nullptr; ctx->packed_version = 0; ctx->pixel_log = nullptr; ctx->pixel_log_u32 = 0; ctx->slot_cost = ctx->slot_order = ctx->order_hist = nullptr; ctx->tile_capacity = ctx->order_tiles = 0;
+  ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr; ctx->queue = nullptr; ctx->packed = nullptr; ctx->packed_of = nullptr; ctx->packed_version = 0; ctx->present = nullptr; ctx->present_bytes = 0; ctx->pixel_log = nullptr; ctx->pixel_log_u32 = 0; ctx->slot_cost = ctx->slot_order = ctx->order_hist = nullptr; ctx->tile_capacity = ctx->order_tiles = 0;
   { const char *nc = getenv("TDT_NO_COST_ORDER"); ctx->no_cost_order = nc && nc[0] == '1'; }
   ctx->scan = nullptr; ctx->max_parent_value = ctx->max_any_value = 0xFFFFFFFFu;
   { hipDeviceProp_t prop; ctx->num_cus = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
@@ -845,6 +861,7 @@ void tdt_ctx_destroy(tdt_ctx *ctx) {
   if (ctx->slot_order) (void)hipFree(ctx->slot_order);
   if (ctx->order_hist) (void)hipFree(ctx->order_hist);
   if (ctx->pixel_log) (void)hipFree(ctx->pixel_log);
+  if (ctx->present) (void)hipFree(ctx->present);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1078,6 +1095,25 @@ int tdt_image_read(tdt_image *img, float *dst) {
   tdt_ctx *ctx = img->ctx;
   TDT_HIP(ctx, hipSetDevice(ctx->device));
   TDT_HIP(ctx, hipMemcpyAsync(dst, img->dev, (size_t)img->w * img->h * 16, hipMemcpyDeviceToHost, ctx->stream));
+  TDT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return TDT_OK;
+}
+
+int tdt_image_read_rgba8(tdt_image *img, int top_down, uint8_t *dst) {
+  if (!img || !dst) return TDT_ERR_INVALID_VALUE;
+  tdt_ctx *ctx = img->ctx;
+  TDT_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = (size_t)img->w * img->h * 4;
+  if (ctx->present_bytes < bytes) {
+    if (ctx->present) (void)hipFree(ctx->present);
+    ctx->present = nullptr; ctx->present_bytes = 0;
+    TDT_HIP(ctx, hipMalloc((void **)&ctx->present, bytes));
+    ctx->present_bytes = bytes;
+  }
+  hipLaunchKernelGGL(tdt::present_kernel, dim3((unsigned)(img->w + 63) / 64, (unsigned)(img->h + 3) / 4), dim3(256), 0, ctx->stream,
+                     (const float4 *)img->dev, ctx->present, img->w, img->h, top_down ? 1 : 0);
+  TDT_HIP(ctx, hipGetLastError());
+  TDT_HIP(ctx, hipMemcpyAsync(dst, ctx->present, bytes, hipMemcpyDeviceToHost, ctx->stream));
   TDT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return TDT_OK;
 }

@@ -26,6 +26,9 @@ class CameraBuilderC(ctypes.Structure):
         ("has_origin", ctypes.c_int32), ("origin", ctypes.c_float * 3),
         ("has_samples_per_pixel", ctypes.c_int32), ("samples_per_pixel", ctypes.c_int32),
         ("has_max_bounce", ctypes.c_int32), ("max_bounce", ctypes.c_int32),
+        ("has_turn_rate", ctypes.c_int32), ("turn_rate", ctypes.c_float),
+        ("has_normal_speed", ctypes.c_int32), ("normal_speed", ctypes.c_float),
+        ("has_sprint_speed", ctypes.c_int32), ("sprint_speed", ctypes.c_float),
     ]
 
 
@@ -42,6 +45,107 @@ class CameraUniforms(ctypes.Structure):
         c = CameraUniforms()
         ctypes.memmove(ctypes.byref(c), ctypes.byref(self), ctypes.sizeof(self))
         return c
+
+
+class CameraSettings(ctypes.Structure):
+    """CameraSettings (camera.rs:9-16) = assets/settings/camera.ron."""
+    _fields_ = [("samples_per_pixel", ctypes.c_int32), ("max_bounce", ctypes.c_int32), ("turn_rate", ctypes.c_float),
+                ("normal_speed", ctypes.c_float), ("sprint_speed", ctypes.c_float)]
+
+    @classmethod
+    def from_ron(cls, text):
+        """ron::de::from_bytes::<CameraSettings> (main.rs:171, 493)."""
+        data = text.encode() if isinstance(text, str) else bytes(text)
+        out = cls()
+        _check(lib().tdt_camera_settings_from_ron(data, len(data), ctypes.byref(out)))
+        return out
+
+
+class CameraC(ctypes.Structure):
+    _fields_ = [("horizontal", ctypes.c_float * 3), ("vertical", ctypes.c_float * 3),
+                ("viewport_width", ctypes.c_float), ("viewport_height", ctypes.c_float),
+                ("lower_left_corner", ctypes.c_float * 3), ("origin", ctypes.c_float * 3),
+                ("pitch", ctypes.c_float * 4), ("yaw", ctypes.c_float * 4),
+                ("image_width", ctypes.c_int32), ("image_height", ctypes.c_int32),
+                ("settings", CameraSettings), ("movement_speed", ctypes.c_float)]
+
+
+# Direction::into_vector3 (utility/mod.rs:15-26)
+DIRECTION = {"Front": (0.0, 0.0, -1.0), "Back": (0.0, 0.0, 1.0), "Rigth": (1.0, 0.0, 0.0), "Left": (-1.0, 0.0, 0.0),
+             "Up": (0.0, 1.0, 0.0), "Down": (0.0, -1.0, 0.0)}
+
+
+class Camera:
+    """The reference's Camera (camera.rs:20-102) without the GL objects: the controller state and the uniforms it sends
+    (cgmath restated, parity unpinned — see include/tdt_host.h)."""
+
+    def __init__(self, vertical_fov, image_width, aspect_ratio=None, viewport_height=None, origin=None, samples_per_pixel=None,
+                 max_bounce=None, turn_rate=None, normal_speed=None, sprint_speed=None):
+        b = _builder(vertical_fov, image_width, aspect_ratio, viewport_height, origin, samples_per_pixel, max_bounce)
+        for name, v in (("turn_rate", turn_rate), ("normal_speed", normal_speed), ("sprint_speed", sprint_speed)):
+            if v is not None:
+                setattr(b, "has_" + name, 1)
+                setattr(b, name, v)
+        self.c = CameraC()
+        _check(lib().tdt_camera_init(ctypes.byref(b), ctypes.byref(self.c)))
+
+    def translate(self, by, deltatime):
+        v = (ctypes.c_float * 3)(*(DIRECTION[by] if isinstance(by, str) else by))
+        _check(lib().tdt_camera_translate(ctypes.byref(self.c), v, ctypes.c_double(deltatime)))
+
+    def turn_pitch(self, angle):
+        _check(lib().tdt_camera_turn_pitch(ctypes.byref(self.c), ctypes.c_float(angle)))
+
+    def turn_yaw(self, angle):
+        _check(lib().tdt_camera_turn_yaw(ctypes.byref(self.c), ctypes.c_float(angle)))
+
+    def set_speed_to_normal(self):
+        lib().tdt_camera_set_speed_to_normal(ctypes.byref(self.c))
+
+    def set_speed_to_sprint(self):
+        lib().tdt_camera_set_speed_to_sprint(ctypes.byref(self.c))
+
+    def look_at_world_point(self, distance):
+        out = (ctypes.c_float * 3)()
+        _check(lib().tdt_camera_look_at_world_point(ctypes.byref(self.c), ctypes.c_float(distance), out))
+        return list(out)
+
+    def apply_settings(self, settings):
+        _check(lib().tdt_camera_apply_settings(ctypes.byref(self.c), ctypes.byref(settings)))
+
+    def uniforms(self):
+        u = CameraUniforms()
+        _check(lib().tdt_camera_get_uniforms(ctypes.byref(self.c), ctypes.byref(u)))
+        return u
+
+
+# ---------------------------------------------------------------- presentation (SURVEY §8f-4) ---
+def present_rgba8(image, top_down=True):
+    """What the reference's quad pass leaves in an RGBA8 back buffer (quad.frag:10, main.rs:582-600) for an (H, W, 4) float32
+    render texture with row 0 at the bottom; host-side counterpart of rt.Texture.read_rgba8."""
+    image = np.ascontiguousarray(image, np.float32)
+    h, w = image.shape[:2]
+    out = np.empty((h, w, 4), np.uint8)
+    _check(lib().tdt_present_rgba8(image.ctypes.data, w, h, 1 if top_down else 0, out.ctypes.data))
+    return out
+
+
+def png_encode(rgba8, with_alpha=False):
+    """8-bit PNG bytes of a top-down (H, W, 4) uint8 frame."""
+    rgba8 = np.ascontiguousarray(rgba8, np.uint8)
+    h, w = rgba8.shape[:2]
+    buf, n = ctypes.c_void_p(), ctypes.c_size_t(0)
+    _check(lib().tdt_png_encode(rgba8.ctypes.data, w, h, 1 if with_alpha else 0, ctypes.byref(buf), ctypes.byref(n)))
+    try:
+        return ctypes.string_at(buf, n.value)
+    finally:
+        lib().tdt_host_free(buf)
+
+
+def png_write(path, rgba8, with_alpha=False):
+    rgba8 = np.ascontiguousarray(rgba8, np.uint8)
+    h, w = rgba8.shape[:2]
+    _check(lib().tdt_png_write(os.fsencode(path), rgba8.ctypes.data, w, h, 1 if with_alpha else 0))
 
 
 class SceneParams(ctypes.Structure):
@@ -73,6 +177,24 @@ def lib():
         L.tdt_scene_blob.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]
         L.tdt_scene_blob.restype = ctypes.c_void_p
         L.tdt_scene_counts.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]
+        L.tdt_camera_init.argtypes = [ctypes.POINTER(CameraBuilderC), ctypes.POINTER(CameraC)]
+        L.tdt_camera_translate.argtypes = [ctypes.POINTER(CameraC), ctypes.POINTER(ctypes.c_float), ctypes.c_double]
+        L.tdt_camera_turn_pitch.argtypes = [ctypes.POINTER(CameraC), ctypes.c_float]
+        L.tdt_camera_turn_yaw.argtypes = [ctypes.POINTER(CameraC), ctypes.c_float]
+        L.tdt_camera_set_speed_to_normal.argtypes = [ctypes.POINTER(CameraC)]
+        L.tdt_camera_set_speed_to_normal.restype = None
+        L.tdt_camera_set_speed_to_sprint.argtypes = [ctypes.POINTER(CameraC)]
+        L.tdt_camera_set_speed_to_sprint.restype = None
+        L.tdt_camera_look_at_world_point.argtypes = [ctypes.POINTER(CameraC), ctypes.c_float, ctypes.POINTER(ctypes.c_float)]
+        L.tdt_camera_apply_settings.argtypes = [ctypes.POINTER(CameraC), ctypes.POINTER(CameraSettings)]
+        L.tdt_camera_get_uniforms.argtypes = [ctypes.POINTER(CameraC), ctypes.POINTER(CameraUniforms)]
+        L.tdt_camera_settings_from_ron.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(CameraSettings)]
+        L.tdt_present_rgba8.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.tdt_png_encode.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+                                     ctypes.POINTER(ctypes.c_size_t)]
+        L.tdt_png_write.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.tdt_host_free.argtypes = [ctypes.c_void_p]
+        L.tdt_host_free.restype = None
         _lib = L
     return _lib
 
@@ -144,9 +266,8 @@ class Scene:
         return sum(a.nbytes for a in self.blobs.values())
 
 
-def camera_build(vertical_fov, image_width, aspect_ratio=None, viewport_height=None, origin=None,
-                 samples_per_pixel=None, max_bounce=None):
-    """CameraBuilder::new(fov, width).with_*().build() -> the uniforms it uploads (camera.rs:119-253)."""
+def _builder(vertical_fov, image_width, aspect_ratio=None, viewport_height=None, origin=None, samples_per_pixel=None,
+             max_bounce=None):
     b = CameraBuilderC()
     b.vertical_fov = vertical_fov
     b.image_width = image_width
@@ -161,6 +282,13 @@ def camera_build(vertical_fov, image_width, aspect_ratio=None, viewport_height=N
         b.has_samples_per_pixel, b.samples_per_pixel = 1, samples_per_pixel
     if max_bounce is not None:
         b.has_max_bounce, b.max_bounce = 1, max_bounce
+    return b
+
+
+def camera_build(vertical_fov, image_width, aspect_ratio=None, viewport_height=None, origin=None,
+                 samples_per_pixel=None, max_bounce=None):
+    """CameraBuilder::new(fov, width).with_*().build() -> the uniforms it uploads (camera.rs:119-253)."""
+    b = _builder(vertical_fov, image_width, aspect_ratio, viewport_height, origin, samples_per_pixel, max_bounce)
     u = CameraUniforms()
     _check(lib().tdt_camera_build(ctypes.byref(b), ctypes.byref(u)))
     return u

@@ -52,6 +52,7 @@ SYMBOLS = [
     ("tdt_image_height", _I, [_P]),
     ("tdt_image_device_ptr", _P, [_P]),
     ("tdt_image_read", _I, [_P, _P]),
+    ("tdt_image_read_rgba8", _I, [_P, _I, _P]),
     ("tdt_dispatch_compute", _I, [_P, _I, _I, _I]),
     ("tdt_set_partition", _I, [_P, _I, _I]),
     ("tdt_dispatch_accumulate", _I, [_P, _I, _I, _I, _I, _I, _P]),
@@ -197,6 +198,13 @@ class Texture:
     def read(self):
         img = np.empty((self._h, self._w, 4), np.float32)
         self.ctx.check(lib().tdt_image_read(self.h, img.ctypes.data))
+        return img
+
+    def read_rgba8(self, top_down=True):
+        """The frame as the reference's quad pass presents it (quad.frag:10, main.rs:582-600): (H, W, 4) uint8, converted on
+        the GPU; top_down=True puts the top scan-line first (image-file order)."""
+        img = np.empty((self._h, self._w, 4), np.uint8)
+        self.ctx.check(lib().tdt_image_read_rgba8(self.h, 1 if top_down else 0, img.ctypes.data))
         return img
 
 

@@ -54,3 +54,42 @@ def test_headless_main_with_one_click_edit(tmp_path):
     assert r.returncode == 0, r.stderr
     assert f"counter {meta['counter_after']}" in r.stdout
     assert (read_pfm4(out).view(np.uint32) == z["image"].view(np.uint32)).all()
+
+
+@pytest.mark.gpu
+def test_headless_main_presents_a_png_and_moves_the_camera(tmp_path):
+    """--png = the quad pass's frame as a file; --settings / --move drive the camera controller
+    (§8f-3) exactly as the Python mirror does, so both hosts must render the same moved frame."""
+    import zlib, struct
+    from tdt4230_project_raytracing_amd import host, rt
+    exe = build.build_demo()
+    ron = tmp_path / "camera.ron"
+    ron.write_text("CameraSettings(samples_per_pixel: 2, max_bounce: 5, turn_rate: 0.05, normal_speed: 0.03, sprint_speed: 0.15)")
+    out, png = str(tmp_path / "frame.pfm"), str(tmp_path / "frame.png")
+    r = subprocess.run([exe, "--size", "160x96", "--settings", str(ron), "--move", "eeSwwNdrj", "--out", out, "--png", png],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "spp 2 bounce 5" in r.stdout
+    # the same session through the Python mirror
+    cam = host.Camera(90.0, 160, aspect_ratio=np.float32(160) / np.float32(96), origin=(0.0, -0.1, -0.3), viewport_height=2.0,
+                      samples_per_pixel=4, max_bounce=6, turn_rate=0.05, normal_speed=0.03, sprint_speed=0.15)
+    cam.apply_settings(host.CameraSettings.from_ron(ron.read_text()))
+    cam.set_speed_to_normal()
+    dt = 1.0 / 60.0
+    for k in "eeSwwNdrj":
+        {"e": lambda: cam.turn_yaw(1.0), "r": lambda: cam.turn_pitch(-1.0), "S": cam.set_speed_to_sprint, "N": cam.set_speed_to_normal,
+         "w": lambda: cam.translate("Front", dt), "d": lambda: cam.translate("Rigth", dt), "j": lambda: cam.translate("Down", dt)}[k]()
+    rr = rt.Renderer(host.Scene.demo(), cam.uniforms())
+    try:
+        want = rr.render()
+        want8 = rr.texture.read_rgba8(top_down=True)
+    finally:
+        rr.close()
+    assert (read_pfm4(out).view(np.uint32) == want.view(np.uint32)).all()
+    moved = np.load(os.path.join(GOLDEN, "demo_160x96_spp4_b6.npz"))["image"]
+    assert (want[..., :3] != moved[..., :3]).any()                     # the camera did move
+    data = open(png, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    idat = data[data.index(b"IDAT") + 4:data.index(b"IEND") - 8]
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(96, 1 + 160 * 3)
+    assert (raw[:, 1:].reshape(96, 160, 3) == want8[..., :3]).all()

@@ -29,7 +29,7 @@ def _camera(meta):
     aspect = float(np.float32(meta["W"]) / np.float32(meta["H"]))
     return host.camera_build(90.0, meta["W"], aspect_ratio=aspect, viewport_height=2.0, origin=meta["origin"],
                              samples_per_pixel=meta["spp"], max_bounce=meta["max_bounce"])
-CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if "math_table" not in p and not os.path.basename(p).startswith("edit_"))
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if "math_table" not in p and not os.path.basename(p).startswith(("edit_", "present_")))
 
 
 def load_case(name):

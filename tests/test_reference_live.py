@@ -34,3 +34,16 @@ def test_reference_work_group_size_and_layout(glref):
         assert out[0] == off, (name, out[0])
         if stride is not None:
             assert out[1] == stride, (name, out[1])
+
+
+def test_presentation_vs_reference_quad_pass_fresh_frames(glref):
+    """quad.vert / quad.frag on llvmpipe against tdt_present_rgba8, on frames the fixtures do not hold."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_py
+    rng = np.random.default_rng(99)
+    for shape in ((33, 70), (64, 64), (5, 257)):
+        img = rng.uniform(-0.2, 1.2, shape + (4,)).astype(np.float32)
+        img[rng.random(shape) < 0.05] = np.float32("nan")
+        got = host.present_rgba8(img, top_down=False)
+        assert (got == oracle_py.glref_present(img)).all(), shape
