@@ -201,7 +201,8 @@ def main():
                        "max_bounce": bounce, "octree_max_depth": scene.max_depth, "octree_cells": scene.counts["cells"],
                        "scene_bytes": scene.nbytes(),
                        "schedule": "global pixel queue; pixels handed out most-expensive-first from the work counts (tree levels, "
-                                   "steps, path events) the previous dispatch recorded per pixel; the first dispatch of a "
+                                   "steps, path events) the previous dispatch recorded per pixel (a bench step repeats the same frame; "
+                                   "when the camera or scene changed, 8x8 tiles are ordered instead); the first dispatch of a "
                                    "context runs in image order (TDT_NO_COST_ORDER=1: always)",
                        "partition": f"32x32 work-groups dealt round-robin over {world} rank(s)" + ("; one RCCL gather + de-interleave per step" if sharded else "")},
             "roofline": roofline,

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
 
   int state = ST_FETCH;
   int x = 0, y = 0; size_t pix = 0;
-  uint32_t pixel_slot = 0, pixel_t0 = 0;            // queue slot (work-group * 1024 + pixel) of the current pixel and when it was started
+  uint32_t pixel_slot = 0;                          // queue slot (work-group * 1024 + pixel) of the current pixel
   int s = 0, loop_count = 0;
   Ray r = {0.f, 0.f, 0.f, 0.f, 0.f, 1.f};
   float ix = 0.f, iy = 0.f, iz = 0.f;                // 1 / direction (ray-invariant, rc:319)
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     // with the lanes still alive so that the survivors do not wait for company that will never come
     const int n_alive = __popcll(m_trav | m_event);
     const int th_now = n_alive == 64 ? threshold : ((threshold * n_alive) >> 6) + 1;
-    if (__popcll(m_event) < th_now && m_trav != 0ull) continue;
+    if ((int)__popcll(m_event) < th_now && m_trav != 0ull) continue;
 
     if (COUNT) evpass_no++;
     if (COUNT) { cnt.event_slots += slot64(); cnt.event_active += (state != ST_TRAVERSE && state != ST_DONE); }
@@ -478,22 +478,36 @@ __device__ __forceinline__ uint32_t order_key(uint32_t c, uint32_t g) {   // lar
   const uint32_t frac = e >= g ? (c >> (e - g)) & ((1u << g) - 1u) : (c << (g - e)) & ((1u << g) - 1u);
   return last - ((e << g) + frac);
 }
-__global__ __launch_bounds__(1024) void order_hist_kernel(const uint32_t *__restrict__ cost, uint32_t n, uint32_t *__restrict__ hist, uint32_t g) {
+// smooth != 0: every aligned run of 64 slots — one 8x8 screen tile of a work-group (decode_pixel) — is keyed by the sum
+// of its costs and stays together, in image order, in the output (used when the inputs changed since the costs were taken).
+__device__ __forceinline__ uint32_t run_cost(uint32_t c) {          // wave-wide sum, saturating
+  unsigned long long t = c;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+  return t > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t;
+}
+__global__ __launch_bounds__(1024) void order_hist_kernel(const uint32_t *__restrict__ cost, uint32_t n, uint32_t *__restrict__ hist, uint32_t g, int smooth) {
   __shared__ uint32_t s_bin[512];
   if (threadIdx.x < 512) s_bin[threadIdx.x] = 0;
   __syncthreads();
-  const uint32_t lo = blockIdx.x * kOrderChunk, hi = lo + kOrderChunk < n ? lo + kOrderChunk : n;
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) atomicAdd(&s_bin[order_key(cost[i], g)], 1u);
+  const uint32_t lo = blockIdx.x * kOrderChunk, hi = lo + kOrderChunk < n ? lo + kOrderChunk : n;   // n is a multiple of 1024
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) {
+    if (smooth) { const uint32_t k = order_key(run_cost(cost[i]), g); if ((threadIdx.x & 63u) == 0) atomicAdd(&s_bin[k], 64u); }
+    else atomicAdd(&s_bin[order_key(cost[i], g)], 1u);
+  }
   __syncthreads();
   if (threadIdx.x < 512 && s_bin[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_bin[threadIdx.x]);
 }
 __global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restrict__ cost, uint32_t n, const uint32_t *__restrict__ hist,
-                                                             uint32_t *__restrict__ cursor, uint32_t *__restrict__ order, uint32_t g) {
+                                                             uint32_t *__restrict__ cursor, uint32_t *__restrict__ order, uint32_t g, int smooth) {
   __shared__ uint32_t s_bin[512], s_base[512];
   if (threadIdx.x < 512) s_bin[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t lo = blockIdx.x * kOrderChunk, hi = lo + kOrderChunk < n ? lo + kOrderChunk : n;
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) atomicAdd(&s_bin[order_key(cost[i], g)], 1u);
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) {
+    if (smooth) { const uint32_t k = order_key(run_cost(cost[i]), g); if ((threadIdx.x & 63u) == 0) atomicAdd(&s_bin[k], 64u); }
+    else atomicAdd(&s_bin[order_key(cost[i], g)], 1u);
+  }
   __syncthreads();
   if (threadIdx.x < 512) {
     uint32_t before = 0;
@@ -503,7 +517,15 @@ __global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restric
   }
   __syncthreads();
   for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) {
-    order[atomicAdd(&s_base[order_key(cost[i], g)], 1u)] = i;
+    if (smooth) {
+      const uint32_t k = order_key(run_cost(cost[i]), g);
+      uint32_t pos = 0;
+      if ((threadIdx.x & 63u) == 0) pos = atomicAdd(&s_base[k], 64u);
+      pos = (uint32_t)__shfl((int)pos, 0, 64);
+      order[pos + (threadIdx.x & 63u)] = i;
+    } else {
+      order[atomicAdd(&s_base[order_key(cost[i], g)], 1u)] = i;
+    }
     cost[i] = 0;
   }
 }
@@ -573,7 +595,8 @@ struct tdt_ctx {
   const tdt_buffer *packed_of;  // which buffer/version `packed` was built from
   unsigned long long packed_version;
   uint32_t *slot_cost, *slot_order, *order_hist;   // per queue slot: cost feedback of the last trace dispatch, the hand-out order derived from it; 2 x 256 sort counters
-  uint32_t tile_capacity, order_tiles; // allocation size (work-groups); number of work-groups slot_order is valid for (0: none)
+  uint32_t tile_capacity, cost_tiles;  // allocation size (work-groups); number of work-groups slot_cost holds the last dispatch's costs for (0: none)
+  unsigned char cost_sig[256];         // what those costs were measured on (camera, octree parameters, buffer versions, partition)
   bool no_cost_order;           // TDT_NO_COST_ORDER=1: always hand work-groups out in image order
   uint32_t *scan;               // device scratch of scan_cells_kernel
   uint32_t max_parent_value, max_any_value;   // its result for `packed_of`
@@ -743,18 +766,43 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
       if (ctx->tile_capacity < (uint32_t)t.owned) {
         if (ctx->slot_cost) (void)hipFree(ctx->slot_cost);
         if (ctx->slot_order) (void)hipFree(ctx->slot_order);
-        ctx->slot_cost = ctx->slot_order = nullptr; ctx->tile_capacity = 0; ctx->order_tiles = 0;
+        ctx->slot_cost = ctx->slot_order = nullptr; ctx->tile_capacity = 0; ctx->cost_tiles = 0;
         TDT_HIP(ctx, hipMalloc((void **)&ctx->slot_cost, (size_t)t.owned * 1024 * sizeof(uint32_t)));
         TDT_HIP(ctx, hipMalloc((void **)&ctx->slot_order, (size_t)t.owned * 1024 * sizeof(uint32_t)));
         if (!ctx->order_hist) TDT_HIP(ctx, hipMalloc((void **)&ctx->order_hist, 1024 * sizeof(uint32_t)));
         ctx->tile_capacity = (uint32_t)t.owned;
       }
-      if (ctx->order_tiles != (uint32_t)t.owned) {   // no usable history: image order, fresh cost array
-        ctx->order_tiles = 0;
-        TDT_HIP(ctx, hipMemsetAsync(ctx->slot_cost, 0, (size_t)t.owned * 1024 * sizeof(uint32_t), ctx->stream));
+      // what this dispatch traces: if it equals what the recorded costs were measured on (a still camera: progressive
+      // passes, repeated frames) every pixel will cost exactly what it did, and pixels are sorted one by one; otherwise
+      // (the camera moved, the scene was edited) only the low-frequency part of the cost image is still true, and 8x8
+      // tiles are sorted by their summed cost — measured on a 60 fps walk, exact-order-of-a-stale-frame is no better
+      // than image order (256^3: 3 % worse), the tile form keeps about half of the gain
+      unsigned char sig[sizeof ctx->cost_sig];
+      std::memset(sig, 0, sizeof sig);
+      {
+        size_t o = 0;
+        auto put = [&](const void *p, size_t n) { if (o + n <= sizeof sig) { std::memcpy(sig + o, p, n); o += n; } };
+        put(&c->image_width, sizeof(int32_t) * 4); put(c->horizontal, sizeof(float) * 12); put(&c->part_rank, sizeof(int) * 2);
+        put(of, sizeof of); put(oi, sizeof oi); put(&k.cover_w, sizeof k.cover_w); put(&k.cover_h, sizeof k.cover_h); put(&img->w, sizeof img->w); put(&img->h, sizeof img->h);
+        for (int sl = 0; sl < kNumSlots; sl++) if (ctx->ssbo[sl]) { put(&ctx->ssbo[sl], sizeof(void *)); put(&ctx->ssbo[sl]->version, sizeof ctx->ssbo[sl]->version); }
       }
       P.slot_cost = ctx->slot_cost;
-      P.slot_order = ctx->order_tiles ? ctx->slot_order : nullptr;
+      if (ctx->cost_tiles == (uint32_t)t.owned) {
+        static const int force_smooth = getenv("TDT_ORDER_SMOOTH") ? atoi(getenv("TDT_ORDER_SMOOTH")) : -1;
+        const int smooth = force_smooth >= 0 ? force_smooth : (std::memcmp(sig, ctx->cost_sig, sizeof sig) != 0 ? 1 : 0);
+        const uint32_t n_slots = (uint32_t)t.owned * 1024u, n_chunks = (n_slots + tdt::kOrderChunk - 1) / tdt::kOrderChunk;
+        const uint32_t og = tdt::kOrderBits;
+        TDT_HIP(ctx, hipMemsetAsync(ctx->order_hist, 0, 1024 * sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(tdt::order_hist_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, n_slots, ctx->order_hist, og, smooth);
+        hipLaunchKernelGGL(tdt::order_scatter_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, n_slots,
+                           ctx->order_hist, ctx->order_hist + 512, ctx->slot_order, og, smooth);   // also clears slot_cost
+        TDT_HIP(ctx, hipGetLastError());
+        P.slot_order = ctx->slot_order;
+      } else {                                        // no usable history: image order, fresh cost array
+        TDT_HIP(ctx, hipMemsetAsync(ctx->slot_cost, 0, (size_t)t.owned * 1024 * sizeof(uint32_t), ctx->stream));
+      }
+      std::memcpy(ctx->cost_sig, sig, sizeof sig);
+      ctx->cost_tiles = (uint32_t)t.owned;            // the kernel launched below records this dispatch's costs
     }
     TDT_HIP(ctx, hipMemsetAsync(ctx->queue, 0, sizeof(unsigned int), ctx->stream));
   }
@@ -792,16 +840,6 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     else hipLaunchKernelGGL(tdt::resolve_kernel, grid4, block4, 0, ctx->stream, P);
 #undef TDT_LAUNCH
     TDT_HIP(ctx, hipGetLastError());
-    if (mode != 2 && P.slot_cost) {
-      const uint32_t n_slots = (uint32_t)t.owned * 1024u, n_chunks = (n_slots + tdt::kOrderChunk - 1) / tdt::kOrderChunk;
-      const uint32_t og = tdt::kOrderBits;
-      TDT_HIP(ctx, hipMemsetAsync(ctx->order_hist, 0, 1024 * sizeof(uint32_t), ctx->stream));
-      hipLaunchKernelGGL(tdt::order_hist_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, n_slots, ctx->order_hist, og);
-      hipLaunchKernelGGL(tdt::order_scatter_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, n_slots,
-                         ctx->order_hist, ctx->order_hist + 512, ctx->slot_order, og);
-      TDT_HIP(ctx, hipGetLastError());
-      ctx->order_tiles = (uint32_t)t.owned;
-    }
   }
   if (counts_out) {
     TDT_HIP(ctx, hipMemcpyAsync(counts_out, ctx->counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
@@ -828,7 +866,7 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
   if (!ctx) return fail(nullptr, TDT_ERR_HIP, "out of host memory");
   ctx->device = device_id;
   for (auto &s : ctx->ssbo) s = nullptr;
-  ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr; ctx->queue = nullptr; ctx->packed = nullptr; ctx->packed_of = nullptr; ctx->packed_version = 0; ctx->present = nullptr; ctx->present_bytes = 0; ctx->pixel_log = nullptr; ctx->pixel_log_u32 = 0; ctx->slot_cost = ctx->slot_order = ctx->order_hist = nullptr; ctx->tile_capacity = ctx->order_tiles = 0;
+  ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr; ctx->queue = nullptr; ctx->packed = nullptr; ctx->packed_of = nullptr; ctx->packed_version = 0; ctx->present = nullptr; ctx->present_bytes = 0; ctx->pixel_log = nullptr; ctx->pixel_log_u32 = 0; ctx->slot_cost = ctx->slot_order = ctx->order_hist = nullptr; ctx->tile_capacity = ctx->cost_tiles = 0;
   { const char *nc = getenv("TDT_NO_COST_ORDER"); ctx->no_cost_order = nc && nc[0] == '1'; }
   ctx->scan = nullptr; ctx->max_parent_value = ctx->max_any_value = 0xFFFFFFFFu;
   { hipDeviceProp_t prop; ctx->num_cus = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }

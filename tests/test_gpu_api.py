@@ -194,6 +194,31 @@ def test_cost_feedback_order_changes_only_the_schedule(oracle, monkeypatch, cfg)
         r.close()
 
 
+def test_cost_feedback_after_the_camera_moved(oracle):
+    """When the inputs of a dispatch differ from what the recorded costs were measured on (camera moved, scene edited),
+    8x8 tiles are ordered by their summed cost instead of single pixels; a repeat of the same view then goes back to
+    the per-pixel order.  Same bits every time."""
+    scene = host.Scene.config(2)
+    cam_a = host.camera_reference_pose(320, 192, 3, 8)
+    moved = host.Camera(90.0, 320, aspect_ratio=np.float32(320) / np.float32(192), origin=(0.0, -0.1, -0.3), viewport_height=2.0,
+                        samples_per_pixel=3, max_bounce=8)
+    moved.turn_yaw(2.0)
+    moved.translate("Front", 0.5)
+    cam_b = moved.uniforms()
+    ref_a, ref_b = oracle.render(scene, cam_a, threads=8), oracle.render(scene, cam_b, threads=8)
+    assert not _eq(ref_a, ref_b)
+    r = rt.Renderer(scene, cam_a)
+    try:
+        assert _eq(r.render(), ref_a)                       # image order
+        rt.initial_uniforms(cam_b, r.shader.program)
+        assert _eq(r.render(), ref_b)                       # tiles ordered by the costs of view A
+        assert _eq(r.render(), ref_b)                       # pixels ordered by the costs of view B
+        rt.initial_uniforms(cam_a, r.shader.program)
+        assert _eq(r.render(), ref_a)
+    finally:
+        r.close()
+
+
 def test_zero_samples_and_zero_bounces(oracle):
     scene = host.Scene.demo()
     for spp, bounce in ((0, 4), (2, 0)):
