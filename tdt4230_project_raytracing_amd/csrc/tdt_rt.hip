@@ -17,9 +17,6 @@
 #include "trace_device.hpp"
 #include "trace_params.h"
 
-#ifndef TDT_MIN_WAVES
-#define TDT_MIN_WAVES 4
-#endif
 #ifndef TDT_BLOCK
 #define TDT_BLOCK 1024      // threads per persistent block; TDT_BLOCKS_PER_CU of them share a CU
 #define TDT_BLOCKS_PER_CU 1
@@ -34,9 +31,10 @@ namespace tdt {
 // t = rank + k * world: SURVEY §8e), p-th pixel inside it in 8x8-tile-major order — and every lane
 // pulls its next pixel from it (one atomic per wave: ballot + prefix count) when it has finished
 // all samples of its current one.  A lane that drew cheap (sky) pixels keeps working instead of
-// idling behind the most expensive pixel of its tile, all CUs stay busy until the queue is empty,
-// and at any moment the chip works on one narrow band of the image, so neighbouring lanes share
-// octree nodes and cache lines.
+// idling behind the most expensive pixel of its tile and all CUs stay busy until the queue is empty.
+// The queue is handed out in slot order — then the chip works on one narrow band of the image at a time and
+// neighbouring lanes share octree nodes and cache lines — or through P.slot_order, a permutation of the slots
+// built from the previous dispatch's per-pixel work counts ("Cost-feedback scheduling" below).
 TDT_DEV void decode_pixel(const TraceParams &P, int k, uint32_t p, int &x, int &y, size_t &pix, bool &inside) {
   const int t = P.part_rank + k * P.part_world;
   const int gx = t % P.tiles_x, gy = t / P.tiles_x;
