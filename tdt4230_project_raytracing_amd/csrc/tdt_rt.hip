@@ -66,10 +66,11 @@ TDT_DEV uint32_t wave_sum(uint32_t v) {
 // of operations for its own pixel, in the same order (bit-identical sums).
 enum : int { ST_TRAVERSE = 0, ST_HIT = 1, ST_END = 2, ST_FETCH = 3, ST_PRIMARY = 4, ST_NEWRAY = 5, ST_DONE = 6 };
 
-// MODE 0: the whole of main() rc:234-252.  MODE 1: only the sample loop, adding to running sums.
+// P.accumulate == 0: the whole of main() rc:234-252; 1: only the sample loop, adding to running sums (a uniform run-time
+// flag, looked at once per pixel, so the scene-specialised variants serve progressive passes too).
 // COUNT: instrumented build that also totals the events defining the algorithmic bytes.
 // POW2: exact-comparison treeLookup (see tree_lookup_pow2) vs the literal float form.
-template <int MODE, bool COUNT, bool POW2, int DEPTH = 0, bool RESIDENT = false, bool SAFEV = false>
+template <bool COUNT, bool POW2, int DEPTH = 0, bool RESIDENT = false, bool SAFEV = false>
 __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   __shared__ __attribute__((aligned(16))) uint16_t s_nodes[kLdsCells * 8 + 8];   // + the sentinel slot
   for (uint32_t i = threadIdx.x * 8u; i < P.lds_nodes; i += (uint32_t)TDT_BLOCK * 8u)      // one cell (8 x u16) per lane and trip
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       if (s < s_end) state = ST_PRIMARY;
       else {
         float4 *dst = reinterpret_cast<float4 *>(P.image) + pix;
-        if (MODE == 1) {
+        if (P.accumulate) {
           *dst = make_float4(sr, sg, sb, 0.f);
           if (P.carry) {
             float4 *c = reinterpret_cast<float4 *>(P.carry) + pix * 4;
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
               n_pixels++;
               sr = 0.f; sg = 0.f; sb = 0.f; s = P.spp_begin;
               pc.root = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}; pc.leaf = pc.root; pc.root_t = 0.f;
-              if (MODE == 1) {
+              if (P.accumulate) {
                 const float4 acc = *(reinterpret_cast<const float4 *>(P.image) + pix);
                 sr = acc.x; sg = acc.y; sb = acc.z;
                 if (P.carry) {
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
                 }
               }
               if (s < s_end) state = ST_PRIMARY;
-              else if (MODE == 0) {                   // zero samples: main() still stores sqrt(0/0) clamped
+              else if (!P.accumulate) {               // zero samples: main() still stores sqrt(0/0) clamped
                 const float n = (float)P.samples_per_pixel;
                 const float v0 = f_min(f_max(__builtin_sqrtf(0.f / n), 0.f), 1.f);
                 *(reinterpret_cast<float4 *>(P.image) + pix) = make_float4(v0, v0, v0, 1.0f);
@@ -819,8 +820,9 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     const bool safev = ctx->max_parent_value < (1u << 22);
     const bool resident = buf_nodes == P.lds_nodes && buf_nodes > 0 && (P.cells_dwords & 1u) == 0 && ctx->max_any_value <= tdt::kPackedMaxValue;
     bool launched = false;
-    if (mode == 0 && !counts_out && pow2 && safev && !ctx->no_specialise) {
-#define TDT_SPEC(D, R) hipLaunchKernelGGL((tdt::trace_kernel<0, false, true, D, R, true>), grid, block, 0, ctx->stream, P); launched = true; break
+    P.accumulate = mode == 1 ? 1 : 0;
+    if (mode != 2 && !counts_out && pow2 && safev && !ctx->no_specialise) {
+#define TDT_SPEC(D, R) hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, R, true>), grid, block, 0, ctx->stream, P); launched = true; break
       if (resident) switch (P.max_depth) {
         case 3: TDT_SPEC(3, true); case 4: TDT_SPEC(4, true); case 5: TDT_SPEC(5, true); case 6: TDT_SPEC(6, true);
         case 7: TDT_SPEC(7, true); default: break; }
@@ -829,12 +831,11 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
         case 10: TDT_SPEC(10, false); default: break; }
 #undef TDT_SPEC
     }
-#define TDT_LAUNCH(M, C) do { if (pow2) hipLaunchKernelGGL((tdt::trace_kernel<M, C, true>), grid, block, 0, ctx->stream, P); \
-                              else hipLaunchKernelGGL((tdt::trace_kernel<M, C, false>), grid, block, 0, ctx->stream, P); } while (0)
+#define TDT_LAUNCH(C) do { if (pow2) hipLaunchKernelGGL((tdt::trace_kernel<C, true>), grid, block, 0, ctx->stream, P); \
+                           else hipLaunchKernelGGL((tdt::trace_kernel<C, false>), grid, block, 0, ctx->stream, P); } while (0)
     if (launched) {}
-    else if (mode == 0 && !counts_out) TDT_LAUNCH(0, false);
-    else if (mode == 0) TDT_LAUNCH(0, true);
-    else if (mode == 1) TDT_LAUNCH(1, false);
+    else if (mode != 2 && !counts_out) TDT_LAUNCH(false);
+    else if (mode != 2) TDT_LAUNCH(true);
     else hipLaunchKernelGGL(tdt::resolve_kernel, grid4, block4, 0, ctx->stream, P);
 #undef TDT_LAUNCH
     TDT_HIP(ctx, hipGetLastError());

@@ -33,6 +33,7 @@ struct TraceParams {
   int32_t owned_tiles;         // work-groups this rank traces
   int32_t part_rank, part_world;  // work-group partition: tile t (row-major) belongs to rank t % world
   int32_t spp_begin, spp_count;   // sample range of this launch
+  int32_t accumulate;             // 0: main() as written (resolve and store); 1: add the samples to the running sums in `image`
   int32_t mode;                // 0 render (sum, sqrt, clamp, store), 1 accumulate into image, 2 resolve
   int32_t total_spp;           // resolve divisor
   int32_t event_threshold;     // > 0: fixed number of lanes that must wait for the event code; 0: adaptive

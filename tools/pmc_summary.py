@@ -7,7 +7,7 @@ for d in sys.argv[1:]:
     for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
         acc = {}
         for r in csv.DictReader(open(f)):
-            if "trace_kernel<0, false" in r["Kernel_Name"]:
+            if "trace_kernel<false" in r["Kernel_Name"]:
                 acc.setdefault(r["Counter_Name"], []).append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
         for k, v in acc.items():
             last = max(i for i, _ in v)
