@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="N>1: weak = N x the pixel rows over the same frustum (per-GPU work fixed); strong = same image")
+    ap.add_argument("--passes", type=int, default=1,
+                    help="N=1 only: a step = one PROGRESSIVE frame of passes x spp samples per pixel (configs[4] is 16 x 64): "
+                         "running sums and hit-record carry through HBM, one resolve at the end (bit-identical to one pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N>1 code path (tile buffer, RCCL gather, de-interleave) even with one rank: a self-test")
@@ -94,6 +97,13 @@ def main():
                             image_ptr=tile_buf.data_ptr(), tile_buffer_tiles=tiles_per_rank)
             gathered = torch.zeros((world, tiles_per_rank, 32, 32, 4), dtype=torch.float32, device=dev) if rank == 0 else None
             full_tex = rt.Texture.wrap_device(r.ctx, full.data_ptr(), IW, IH, bind=False) if rank == 0 else None
+    carry = None
+    if args.passes > 1:
+        if sharded:
+            raise SystemExit("--passes is a single-GPU option")
+        with torch.cuda.stream(stream):
+            carry = torch.zeros((IH, IW, 16), dtype=torch.float32, device=dev)
+        args.no_cpu_baseline = True
     my_pixels = r.shader.covered_pixels(dw, dh)
     if sharded:
         assert r.shader.owned_tiles(dw, dh)[0] <= tiles_per_rank
@@ -105,10 +115,18 @@ def main():
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
-            r.shader.dispatch_compute(dw, dh, 1)
+            if carry is None:
+                r.shader.dispatch_compute(dw, dh, 1)
+            else:
+                full.zero_(); carry.zero_()
+                r.shader.dispatch_accumulate(dw, dh, 1, 0, spp, carry.data_ptr())
             if timed:
                 e1.record(stream)
                 ev_pairs.append((e0, e1))
+            if carry is not None:
+                for k in range(1, args.passes):
+                    r.shader.dispatch_accumulate(dw, dh, 1, k * spp, spp, carry.data_ptr())
+                r.shader.dispatch_resolve(dw, dh, 1, spp * args.passes)
             if sharded:
                 glist = list(gathered.unbind(0)) if rank == 0 else None
                 dist.gather(tile_buf, glist, dst=0)
@@ -138,7 +156,7 @@ def main():
     else:
         total_pixels = float(my_pixels)
     ms_per_step = dt / args.steps * 1e3
-    samples_per_step = total_pixels * spp
+    samples_per_step = total_pixels * spp * args.passes
     value = samples_per_step / (dt / args.steps) / 1e6
 
     # --- roofline of the dominant kernel (the trace kernel), measured on rank 0 -----------------
@@ -191,13 +209,14 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "Mray-samples/sec at 1080p/64spp/depth-8" if args.config == 2 and spp == 64 else f"Mray-samples/sec (config {args.config}, {spp} spp)",
+            "metric": "Mray-samples/sec at 1080p/64spp/depth-8" if args.config == 2 and spp == 64 and args.passes == 1 else f"Mray-samples/sec (config {args.config}, {spp * args.passes} spp" + (f" as {args.passes} progressive passes" if args.passes > 1 else "") + ")",
             "value": round(value, 2), "unit": "Mray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc + (f"; x{rows_factor} pixel rows over the same frustum (weak scaling)" if rows_factor > 1 else ""),
-                       "image": [IW, IH], "dispatch": [dw, dh, 1], "written_pixels": int(total_pixels), "spp": spp,
+                       "image": [IW, IH], "dispatch": [dw, dh, 1], "written_pixels": int(total_pixels), "spp": spp * args.passes,
+                       "passes": args.passes,
                        "max_bounce": bounce, "octree_max_depth": scene.max_depth, "octree_cells": scene.counts["cells"],
                        "scene_bytes": scene.nbytes(),
                        "schedule": "global pixel queue; pixels handed out most-expensive-first from the work counts (tree levels, "
