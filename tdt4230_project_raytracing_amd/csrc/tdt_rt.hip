@@ -246,7 +246,10 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
           const unsigned long long d = (__builtin_amdgcn_s_memrealtime() - pixel_rt0) / 10000ull;   // 0.1 ms bins
           atomicAdd(&P.counters[32 + 16384 + (wave_drained ? 128 : 0) + (d > 127ull ? 127ull : d)], 1ull);
         }
-        if (P.slot_cost) P.slot_cost[pixel_slot] = lane_work | 1u;
+        if (P.slot_cost) {                            // running sum over the dispatches that traced these same inputs
+          const uint32_t before = P.slot_cost[pixel_slot], sum = before + (lane_work | 1u);
+          P.slot_cost[pixel_slot] = sum < before ? 0xFFFFFFFFu : sum;
+        }
         state = ST_FETCH;
       }
     }
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(1024) void order_hist_kernel(const uint32_t *__rest
   if (threadIdx.x < 512 && s_bin[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_bin[threadIdx.x]);
 }
 __global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restrict__ cost, uint32_t n, const uint32_t *__restrict__ hist,
-                                                             uint32_t *__restrict__ cursor, uint32_t *__restrict__ order, uint32_t g, int smooth) {
+                                                             uint32_t *__restrict__ cursor, uint32_t *__restrict__ order, uint32_t g, int smooth, int clear) {
   __shared__ uint32_t s_bin[512], s_base[512];
   if (threadIdx.x < 512) s_bin[threadIdx.x] = 0;
   __syncthreads();
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restric
     } else {
       order[atomicAdd(&s_base[order_key(cost[i], g)], 1u)] = i;
     }
-    cost[i] = 0;
+    if (clear) cost[i] = 0;
   }
 }
 
@@ -594,6 +597,7 @@ struct tdt_ctx {
   const tdt_buffer *packed_of;  // which buffer/version `packed` was built from
   unsigned long long packed_version;
   uint32_t *slot_cost, *slot_order, *order_hist;   // per queue slot: cost feedback of the last trace dispatch, the hand-out order derived from it; 2 x 256 sort counters
+  uint32_t cost_dispatches;            // dispatches summed into slot_cost so far
   uint32_t tile_capacity, cost_tiles;  // allocation size (work-groups); number of work-groups slot_cost holds the last dispatch's costs for (0: none)
   unsigned char cost_sig[256];         // what those costs were measured on (camera, octree parameters, buffer versions, partition)
   bool no_cost_order;           // TDT_NO_COST_ORDER=1: always hand work-groups out in image order
@@ -789,16 +793,22 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
       if (ctx->cost_tiles == (uint32_t)t.owned) {
         static const int force_smooth = getenv("TDT_ORDER_SMOOTH") ? atoi(getenv("TDT_ORDER_SMOOTH")) : -1;
         const int smooth = force_smooth >= 0 ? force_smooth : (std::memcmp(sig, ctx->cost_sig, sizeof sig) != 0 ? 1 : 0);
+        // same inputs again (progressive passes, repeated frames): keep adding to the costs — every pass sharpens the
+        // estimate of what a pixel costs; otherwise start over
+        static const bool no_accum = getenv("TDT_NO_COST_ACCUM") != nullptr;
+        const bool keep_costs = !smooth && !no_accum && ctx->cost_dispatches < 256;   // (restart before the sums can saturate)
+        ctx->cost_dispatches = keep_costs ? ctx->cost_dispatches + 1 : 0;
         const uint32_t n_slots = (uint32_t)t.owned * 1024u, n_chunks = (n_slots + tdt::kOrderChunk - 1) / tdt::kOrderChunk;
         const uint32_t og = tdt::kOrderBits;
         TDT_HIP(ctx, hipMemsetAsync(ctx->order_hist, 0, 1024 * sizeof(uint32_t), ctx->stream));
         hipLaunchKernelGGL(tdt::order_hist_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, n_slots, ctx->order_hist, og, smooth);
         hipLaunchKernelGGL(tdt::order_scatter_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, n_slots,
-                           ctx->order_hist, ctx->order_hist + 512, ctx->slot_order, og, smooth);   // also clears slot_cost
+                           ctx->order_hist, ctx->order_hist + 512, ctx->slot_order, og, smooth, keep_costs ? 0 : 1);
         TDT_HIP(ctx, hipGetLastError());
         P.slot_order = ctx->slot_order;
       } else {                                        // no usable history: image order, fresh cost array
         TDT_HIP(ctx, hipMemsetAsync(ctx->slot_cost, 0, (size_t)t.owned * 1024 * sizeof(uint32_t), ctx->stream));
+        ctx->cost_dispatches = 0;
       }
       std::memcpy(ctx->cost_sig, sig, sizeof sig);
       ctx->cost_tiles = (uint32_t)t.owned;            // the kernel launched below records this dispatch's costs
@@ -865,7 +875,7 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
   if (!ctx) return fail(nullptr, TDT_ERR_HIP, "out of host memory");
   ctx->device = device_id;
   for (auto &s : ctx->ssbo) s = nullptr;
-  ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr; ctx->queue = nullptr; ctx->packed = nullptr; ctx->packed_of = nullptr; ctx->packed_version = 0; ctx->present = nullptr; ctx->present_bytes = 0; ctx->pixel_log = nullptr; ctx->pixel_log_u32 = 0; ctx->slot_cost = ctx->slot_order = ctx->order_hist = nullptr; ctx->tile_capacity = ctx->cost_tiles = 0;
+  ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr; ctx->queue = nullptr; ctx->packed = nullptr; ctx->packed_of = nullptr; ctx->packed_version = 0; ctx->present = nullptr; ctx->present_bytes = 0; ctx->pixel_log = nullptr; ctx->pixel_log_u32 = 0; ctx->slot_cost = ctx->slot_order = ctx->order_hist = nullptr; ctx->tile_capacity = ctx->cost_tiles = 0; ctx->cost_dispatches = 0;
   { const char *nc = getenv("TDT_NO_COST_ORDER"); ctx->no_cost_order = nc && nc[0] == '1'; }
   ctx->scan = nullptr; ctx->max_parent_value = ctx->max_any_value = 0xFFFFFFFFu;
   { hipDeviceProp_t prop; ctx->num_cus = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
