@@ -79,8 +79,13 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   if (threadIdx.x < 16 && P.lds_nodes + threadIdx.x < ((P.lds_nodes + 7u) & ~7u) + 8u)
     s_nodes[P.lds_nodes + threadIdx.x] = (uint16_t)((RESIDENT && POW2) ? 0u : kPackedEscape);
   __syncthreads();
+  __shared__ uint32_t s_grid[512];
+  __shared__ int s_grid_ok;
+  constexpr bool kUseGrid = !COUNT && POW2 && SAFEV && !RESIDENT && DEPTH >= 3;   // see build_top_grid
+  if (kUseGrid) build_top_grid(s_nodes, P.lds_nodes, DEPTH, s_grid, &s_grid_ok);
   NodeSource ns;
   ns.lds = s_nodes; ns.lds_nodes = P.lds_nodes; ns.lds_cells = (P.lds_nodes + 7u) >> 3;
+  ns.grid = s_grid; ns.grid_ok = kUseGrid ? (__builtin_amdgcn_readfirstlane(s_grid_ok) != 0) : false;
   ns.cells = __builtin_amdgcn_make_buffer_rsrc((void *)P.cells, 0, (int)((P.cells_dwords >> 1) << 3), 0x00020000);
   const uint32_t total_slots = (uint32_t)P.owned_tiles * 1024u;
 
@@ -402,6 +407,25 @@ __global__ __launch_bounds__(256) void selftest_kernel(int which, unsigned long 
   for (uint32_t k = 0; k < (0xFFFFFFFFu / stride) + 1u; k++, i += stride) {
     if (k > 0 && i < stride) break;                   // wrapped
     const float x = __uint_as_float(i);
+    if (which == 5 || which == 6) {
+      // build_top_grid's claim, for EVERY coordinate c in [0,1) and every cell index v < 128: outside the bands
+      // (|8c - rint(8c)| > kGridBand) the x decision of levels 1..3 is the plain binary digit of c and never 2v+2.
+      // which == 6 checks the harness: with the band test removed the claim must fail.
+      if (!(x >= 0.0f && x < 1.0f)) continue;
+      const float t8 = x * 8.0f;
+      if (which == 5 && !(__builtin_fabsf(t8 - __builtin_rintf(t8)) > kGridBand)) continue;
+      const uint32_t x3 = (uint32_t)t8;
+      for (int l = 1; l <= 3; l++) {
+        const float f = l == 1 ? x : f_fract_nonneg(x * (float)(1 << (l - 1)));
+        const uint32_t digit = (x3 >> (3 - l)) & 1u;
+        for (uint32_t v = 0; v < 128u; v++) {
+          const float fv = (float)v, q = (fv + f) - fv;
+          const uint32_t qa = q > 0.5f ? 1u : 0u, qb = q == 1.0f ? 1u : 0u;
+          bad += (qa != digit || qb != 0u) ? 1u : 0u;
+        }
+      }
+      continue;
+    }
     float a, b;
     if (which == 0) { a = q_rcp(x); b = 1.0f / x; }
     else if (which == 1) { a = q_sqrt(x); b = __builtin_sqrtf(x); }
@@ -1263,7 +1287,7 @@ int tdt_debug_wave_ends(tdt_ctx *ctx, uint64_t *out, int n) {
 /* Exhaustive self-test of the kernels' short correctly-rounded rcp / sqrt / rsq forms against the
  * IEEE expressions on all 2^32 inputs; *mismatches must come back 0 (which: 0 rcp, 1 sqrt, 2 rsq). */
 int tdt_selftest(tdt_ctx *ctx, int which, uint64_t *mismatches) {
-  if (!ctx || !mismatches || which < 0 || which > 4) return TDT_ERR_INVALID_VALUE;
+  if (!ctx || !mismatches || which < 0 || which > 6) return TDT_ERR_INVALID_VALUE;
   TDT_HIP(ctx, hipSetDevice(ctx->device));
   if (!ctx->counters) TDT_HIP(ctx, hipMalloc((void **)&ctx->counters, (32 + 16384 + 256) * sizeof(unsigned long long)));
   TDT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));

@@ -74,3 +74,26 @@ def test_event_counts_equal_oracle(oracle):
     assert _bits_equal(img, ref).all()
     for k in ("pixels", "octree_hit_calls", "iterations", "node_loads", "lambertian", "metal", "dielectric", "unknown_material"):
         assert got[k] == st[k], (k, got[k], st[k])
+
+
+def test_relocated_top_cells_disable_the_jump_table(oracle):
+    """The top-3-level jump table (build_top_grid) is exact only while the top PARENT nodes point at cell indices < 128.
+    A tree whose first-level cell was re-allocated at the end of the buffer (what octree_update.comp's allocator does to
+    edited trees) must fall back to the level-by-level descent and still match the oracle bit for bit."""
+    scene = host.Scene.config(3)                                  # 256^3: not LDS-resident -> the table is in use
+    cells = scene.blobs[0].reshape(-1, 8, 2).copy()
+    n = cells.shape[0]
+    j = int(np.nonzero(cells[0, :, 1] == 1)[0][0])                # a PARENT node of the root cell
+    moved = cells[int(cells[0, j, 0])].copy()
+    cells = np.concatenate([cells, moved[None]], axis=0)
+    cells[0, j, 0] = n                                            # ... now lives in cell n (>= 128)
+    scene.blobs[0] = np.ascontiguousarray(cells.reshape(-1))
+    cam = host.camera_reference_pose(256, 160, 2, 6)
+    ref = oracle.render(scene, cam, threads=8)
+    r = rt.Renderer(scene, cam)
+    try:
+        for _ in range(2):
+            got = r.render()
+            assert (got.view(np.uint32) == ref.view(np.uint32)).all()
+    finally:
+        r.close()
