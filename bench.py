@@ -42,6 +42,9 @@ def main():
                     help="N=1 only: a step = one PROGRESSIVE frame of passes x spp samples per pixel (configs[4] is 16 x 64): "
                          "running sums and hit-record carry through HBM, one resolve at the end (bit-identical to one pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="torch.distributed backend of the N>1 gather; gloo (through host memory) lets several ranks share "
+                         "one GPU to rehearse the multi-rank path on a single-GPU box")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N>1 code path (tile buffer, RCCL gather, de-interleave) even with one rank: a self-test")
     args = ap.parse_args()
@@ -60,13 +63,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the trace has no CPU path")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()              # rehearsal: ranks may share a device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or args.force_dist
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     W, H, spp, bounce, desc = WORKLOADS[args.config]
     if args.spp:
@@ -128,8 +136,16 @@ def main():
                     r.shader.dispatch_accumulate(dw, dh, 1, k * spp, spp, carry.data_ptr())
                 r.shader.dispatch_resolve(dw, dh, 1, spp * args.passes)
             if sharded:
-                glist = list(gathered.unbind(0)) if rank == 0 else None
-                dist.gather(tile_buf, glist, dst=0)
+                if args.backend == "nccl":
+                    glist = list(gathered.unbind(0)) if rank == 0 else None
+                    dist.gather(tile_buf, glist, dst=0)
+                else:                                        # rehearsal path: gloo gathers host tensors
+                    stream.synchronize()
+                    host_buf = tile_buf.cpu()
+                    hlist = [torch.empty_like(host_buf) for _ in range(world)] if rank == 0 else None
+                    dist.gather(host_buf, hlist, dst=0)
+                    if rank == 0:
+                        gathered.copy_(torch.stack(hlist))
                 if rank == 0:
                     r.shader.assemble_tiles(gathered.data_ptr(), world, tiles_per_rank, full_tex, dw, dh)
 
@@ -146,7 +162,7 @@ def main():
         step(True)
     fence()
     dt = time.perf_counter() - t0
-    tt = torch.tensor([dt, float(my_pixels)], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt, float(my_pixels)], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
     if sharded:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
