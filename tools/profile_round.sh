@@ -11,4 +11,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/stats_c3
 python bench.py --steps 10 --warmup 2 > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err
 python bench.py --steps 5 --warmup 2 --config 3 --no-cpu-baseline > gpurun_out/$TAG/bench_c3.json 2>> gpurun_out/$TAG/bench.err
 python bench.py --steps 5 --warmup 2 --config 5 --no-cpu-baseline > gpurun_out/$TAG/bench_c5.json 2>> gpurun_out/$TAG/bench.err
+python bench.py --steps 2 --warmup 1 --config 5 --passes 16 > gpurun_out/$TAG/bench_c5_progressive.json 2>> gpurun_out/$TAG/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/stats_c5 -- python bench.py --steps 8 --warmup 1 --no-cpu-baseline --config 5 > gpurun_out/$TAG/bench_stats_c5.log 2>&1
 ls gpurun_out/$TAG
