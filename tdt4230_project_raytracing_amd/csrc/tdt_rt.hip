@@ -102,6 +102,8 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   int state = ST_FETCH;
   int x = 0, y = 0; size_t pix = 0;
   uint32_t pixel_slot = 0;                          // queue slot (work-group * 1024 + pixel) of the current pixel
+  const bool exact_draw = P.plan != nullptr && __builtin_amdgcn_readfirstlane((int)P.plan[0]) != 0;
+  uint32_t buf_slot = 0xFFFFFFFFu, buf_next = 0u, buf_count = 0u, buf_base = 0u;   // the wave's batch of queue slots: lane i holds the i-th; dealt / size / where it started
   int s = 0, loop_count = 0;
   Ray r = {0.f, 0.f, 0.f, 0.f, 0.f, 1.f};
   float ix = 0.f, iy = 0.f, iz = 0.f;                // 1 / direction (ray-invariant, rc:319)
@@ -125,6 +127,10 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   uint32_t w_steps = 0, w_rays = 0, lane_work = 0;
   int threshold = P.event_threshold > 0 ? P.event_threshold : 24;
 
+  // region timers of the instrumented build (s_memtime, wave-uniform): 0 traversal step, 1 gate, 2 hit + scatter, 3 end of path,
+  // 4 pixel fetch, 5 primary ray + threshold, 6 new-ray prologue -> counters[24..30]
+  unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
+#define TDT_TICK(i) do { if (COUNT) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tacc[i] += n_ - tlast; tlast = n_; } } while (0)
   for (;;) {
     if (COUNT) pass_no++;
     // ------------------------------------------------------------ one traversal step rc:410-447
@@ -177,6 +183,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       }
     }
 
+    TDT_TICK(0);
     // ------------------------------------------------------------ path events
     const unsigned long long m_trav = __ballot(state == ST_TRAVERSE);
     const unsigned long long m_event = __ballot(state != ST_TRAVERSE && state != ST_DONE);
@@ -188,7 +195,8 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     // with the lanes still alive so that the survivors do not wait for company that will never come
     const int n_alive = __popcll(m_trav | m_event);
     const int th_now = n_alive == 64 ? threshold : ((threshold * n_alive) >> 6) + 1;
-    if ((int)__popcll(m_event) < th_now && m_trav != 0ull) continue;
+    if ((int)__popcll(m_event) < th_now && m_trav != 0ull) { TDT_TICK(1); continue; }
+    TDT_TICK(1);
 
     if (COUNT) evpass_no++;
     if (COUNT) { cnt.event_slots += slot64(); cnt.event_active += (state != ST_TRAVERSE && state != ST_DONE); }
@@ -211,6 +219,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
         state = ST_END;
       }
     }
+    TDT_TICK(2);
     if (state == ST_END) {                            // rc:297-301, rc:246
       float cr, cg, cb;
       if (loop_count > 0) { cr = ar; cg = ag; cb = ab; }
@@ -251,28 +260,46 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
           const unsigned long long d = (__builtin_amdgcn_s_memrealtime() - pixel_rt0) / 10000ull;   // 0.1 ms bins
           atomicAdd(&P.counters[32 + 16384 + (wave_drained ? 128 : 0) + (d > 127ull ? 127ull : d)], 1ull);
         }
-        if (P.slot_cost) {                            // running sum over the dispatches that traced these same inputs
-          const uint32_t before = P.slot_cost[pixel_slot], sum = before + (lane_work | 1u);
-          P.slot_cost[pixel_slot] = sum < before ? 0xFFFFFFFFu : sum;
-        }
+        if (P.slot_cost) P.slot_cost[pixel_slot] = lane_work | 1u;   // a store: nothing to wait for (the sort adds it up)
         state = ST_FETCH;
       }
     }
+    TDT_TICK(3);
     {                                                 // next pixel from the block queue
-      const bool want = state == ST_FETCH;
-      const unsigned long long m = __ballot(want);
-      if (m != 0ull) {
-        uint32_t base = 0;
-        if ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(P.queue, (uint32_t)__popcll(m));
-        base = (uint32_t)__shfl((int)base, __builtin_ctzll(m), 64);
-        if (COUNT && base + 64u > total_slots) wave_drained = true;
-        if (want) {
-          const uint32_t q = base + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
-          if (q >= total_slots) { state = ST_DONE; if (COUNT) atomicMin(&P.counters[22], __builtin_amdgcn_s_memrealtime()); }
+      // Slots are drawn from the queue up to 64 at a time — one atomic and one coalesced read of the hand-out order per wave
+      // and refill — into buf_slot (lane i holds the i-th slot of the batch) and dealt to the lanes that ask, in lane
+      // order, through a wave-uniform cursor.  (A lane-by-lane atomic + dependent order read stalled the whole wave for
+      // the round trip every time ONE lane finished a pixel: 9 % of the frame.)
+      bool want = state == ST_FETCH;
+      unsigned long long m = __ballot(want);
+      while (m != 0ull) {
+        if (buf_next >= buf_count) {                  // refill: guided self-scheduling — 64 slots while plenty are left,
+          // fewer towards the end of the queue (slots parked in one wave's batch are out of reach of idle lanes elsewhere)
+          // 64 at a time, unless the frame has pixels so long (order_plan_kernel) that a slot parked in one wave's batch
+          // while its other lanes are still busy would start too late: then exactly as many as are asked for
+          const uint32_t chunk = exact_draw ? (uint32_t)__popcll(m) : 64u;
+          uint32_t base = 0;
+          if ((threadIdx.x & 63) == 0) base = atomicAdd(P.queue, chunk);
+          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+          const uint32_t bq = base + (threadIdx.x & 63u);
+          buf_slot = ((threadIdx.x & 63u) < chunk && bq < total_slots) ? (P.slot_order ? P.slot_order[bq] : bq) : 0xFFFFFFFFu;
+          buf_next = 0u; buf_count = chunk; buf_base = base;
+          if (COUNT && base + chunk > total_slots) wave_drained = true;
+        }
+        const uint32_t rank = (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+        const uint32_t avail = buf_count - buf_next;
+        const uint32_t got = (uint32_t)__shfl((int)buf_slot, (int)((buf_next + rank) & 63u), 64);
+        const bool served = want && rank < avail;
+        buf_next += (uint32_t)__popcll(m) < avail ? (uint32_t)__popcll(m) : avail;
+        m = __ballot(want && !served);
+        if (served) {
+          want = false;
+          const uint32_t q = got;
+          if (q == 0xFFFFFFFFu) { state = ST_DONE; if (COUNT) atomicMin(&P.counters[22], __builtin_amdgcn_s_memrealtime()); }
           else {
             if (COUNT) { pixel_rt0 = __builtin_amdgcn_s_memrealtime(); lane_S = 0; lane_E = 0; pixel_pass0 = pass_no; pixel_evpass0 = evpass_no; }
             bool inside;
-            pixel_slot = P.slot_order ? P.slot_order[q] : q;
+            pixel_slot = q;
             decode_pixel(P, (int)(pixel_slot >> 10), pixel_slot & 1023u, x, y, pix, inside);
             lane_work = 0u;
             if (inside) {                             // outside the covered image: ask again next time
@@ -300,6 +327,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
         }
       }
     }
+    TDT_TICK(4);
     if (state == ST_PRIMARY) {                        // rc:240-245
       r = primary_ray(P, x, y, s);
       loop_count = 0; ar = 1.f; ag = 1.f; ab = 1.f;
@@ -312,6 +340,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       const int th = (int)est;
       threshold = w_rays < 256u ? 24 : (th < 2 ? 2 : (th > 40 ? 40 : th));
     }
+    TDT_TICK(5);
     if (state == ST_NEWRAY) {                         // while-condition rc:271 + OctreeHit prologue rc:399-408
       if (!(loop_count < P.max_bounce)) state = ST_END;
       else {
@@ -336,7 +365,9 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
         state = ST_TRAVERSE;
       }
     }
+    TDT_TICK(6);
   }
+#undef TDT_TICK
 
   if (COUNT) {
     // wave timeline (diagnostics): [18] earliest start, [19] latest end, [20] sum of wave end times, [21] waves
@@ -346,6 +377,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       atomicAdd(&P.counters[20], t_end - wave_t0); atomicAdd(&P.counters[21], 1ull);
       P.counters[32 + blockIdx.x * (TDT_BLOCK / 64) + (threadIdx.x >> 6)] = t_end;   // per-wave end time (grid <= 256 blocks... see kWaveLog)
     }
+    if ((threadIdx.x & 63) == 0) for (int i = 0; i < 7; i++) atomicAdd(&P.counters[24 + i], tacc[i]);
     uint32_t v[18] = {n_pixels, cnt.octree_hit_calls, cnt.iterations, cnt.node_loads,
                       cnt.lambertian, cnt.metal, cnt.dielectric, cnt.unknown,
                       cnt.trav_slots, cnt.trav_active, cnt.level_slots, cnt.level_active, cnt.event_slots, cnt.event_active,
@@ -512,27 +544,31 @@ __device__ __forceinline__ uint32_t run_cost(uint32_t c) {          // wave-wide
   for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
   return t > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t;
 }
-__global__ __launch_bounds__(1024) void order_hist_kernel(const uint32_t *__restrict__ cost, uint32_t n, uint32_t *__restrict__ hist, uint32_t g, int smooth) {
+__global__ __launch_bounds__(1024) void order_hist_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ acc, uint32_t n, uint32_t *__restrict__ hist, uint32_t g, int smooth, int keep) {
   __shared__ uint32_t s_bin[512];
   if (threadIdx.x < 512) s_bin[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t lo = blockIdx.x * kOrderChunk, hi = lo + kOrderChunk < n ? lo + kOrderChunk : n;   // n is a multiple of 1024
   for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) {
-    if (smooth) { const uint32_t k = order_key(run_cost(cost[i]), g); if ((threadIdx.x & 63u) == 0) atomicAdd(&s_bin[k], 64u); }
-    else atomicAdd(&s_bin[order_key(cost[i], g)], 1u);
+    // acc = the cost estimate the order is built from: this dispatch's costs, added to those of the earlier dispatches
+    // that traced the same inputs (keep) — every pass sharpens the estimate — or on their own
+    const uint32_t c = cost[i], before = keep ? acc[i] : 0u, a = before + c < before ? 0xFFFFFFFFu : before + c;
+    acc[i] = a;
+    if (smooth) { const uint32_t k = order_key(run_cost(a), g); if ((threadIdx.x & 63u) == 0) atomicAdd(&s_bin[k], 64u); }
+    else atomicAdd(&s_bin[order_key(a, g)], 1u);
   }
   __syncthreads();
   if (threadIdx.x < 512 && s_bin[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_bin[threadIdx.x]);
 }
-__global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restrict__ cost, uint32_t n, const uint32_t *__restrict__ hist,
-                                                             uint32_t *__restrict__ cursor, uint32_t *__restrict__ order, uint32_t g, int smooth, int clear) {
+__global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restrict__ cost, const uint32_t *__restrict__ acc, uint32_t n, const uint32_t *__restrict__ hist,
+                                                             uint32_t *__restrict__ cursor, uint32_t *__restrict__ order, uint32_t g, int smooth) {
   __shared__ uint32_t s_bin[512], s_base[512];
   if (threadIdx.x < 512) s_bin[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t lo = blockIdx.x * kOrderChunk, hi = lo + kOrderChunk < n ? lo + kOrderChunk : n;
   for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) {
-    if (smooth) { const uint32_t k = order_key(run_cost(cost[i]), g); if ((threadIdx.x & 63u) == 0) atomicAdd(&s_bin[k], 64u); }
-    else atomicAdd(&s_bin[order_key(cost[i], g)], 1u);
+    if (smooth) { const uint32_t k = order_key(run_cost(acc[i]), g); if ((threadIdx.x & 63u) == 0) atomicAdd(&s_bin[k], 64u); }
+    else atomicAdd(&s_bin[order_key(acc[i], g)], 1u);
   }
   __syncthreads();
   if (threadIdx.x < 512) {
@@ -544,15 +580,45 @@ __global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restric
   __syncthreads();
   for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) {
     if (smooth) {
-      const uint32_t k = order_key(run_cost(cost[i]), g);
+      const uint32_t k = order_key(run_cost(acc[i]), g);
       uint32_t pos = 0;
       if ((threadIdx.x & 63u) == 0) pos = atomicAdd(&s_base[k], 64u);
       pos = (uint32_t)__shfl((int)pos, 0, 64);
       order[pos + (threadIdx.x & 63u)] = i;
     } else {
-      order[atomicAdd(&s_base[order_key(cost[i], g)], 1u)] = i;
+      order[atomicAdd(&s_base[order_key(acc[i], g)], 1u)] = i;
     }
-    if (clear) cost[i] = 0;
+    cost[i] = 0;
+  }
+}
+
+// How the next dispatch draws slots from the queue (see the fetch code of trace_kernel): plan[0] = 1 -> exactly as asked,
+// 0 -> in batches of 64.  Batches make a wave's 64 pixels alike (4K/256^3: -9 %) and spare most queue round trips, but a
+// slot parked in a batch starts late, which costs more than it gains once single pixels are long against the frame
+// (1080p/512^3, where a pixel can take 40 % of the frame: +4 %).  From the cost histogram: f = c_hi * lanes / sum(cost) is the
+// share of the frame a pixel of the 99.9th cost percentile occupies its lane for; exact drawing when f > max_share.
+__global__ __launch_bounds__(512) void order_plan_kernel(const uint32_t *__restrict__ hist, uint32_t g, uint32_t lanes, float max_share,
+                                                         uint32_t *__restrict__ plan) {
+  __shared__ float s_sum[512];
+  __shared__ uint32_t s_cnt[512];
+  const uint32_t bins = 32u << g, k = threadIdx.x;
+  float rep = 0.f; uint32_t cnt = 0;
+  if (k < bins - 1u) {                                // the last bin holds the never-run slots (cost 0)
+    const uint32_t idx = (bins - 1u) - k, e = idx >> g, frac = idx & ((1u << g) - 1u);
+    rep = __builtin_ldexpf(1.0f + (float)frac / (float)(1u << g), (int)e);
+    cnt = hist[k];
+  }
+  s_sum[k] = rep * (float)cnt; s_cnt[k] = cnt;
+  __syncthreads();
+  if (k == 0) {
+    float total = 0.f; uint32_t n = 0;
+    for (uint32_t b = 0; b < bins; b++) { total += s_sum[b]; n += s_cnt[b]; }
+    uint32_t acc = 0, hi_bin = 0;
+    const uint32_t want = n / 1000u + 1u;
+    for (uint32_t b = 0; b < bins; b++) { acc += s_cnt[b]; if (acc >= want) { hi_bin = b; break; } }
+    const uint32_t idx = (bins - 1u) - hi_bin, e = idx >> g, frac = idx & ((1u << g) - 1u);
+    const float c_hi = __builtin_ldexpf(1.0f + (float)frac / (float)(1u << g), (int)e);
+    plan[0] = (total > 0.f && c_hi * (float)lanes > max_share * total) ? 1u : 0u;
   }
 }
 
@@ -620,7 +686,7 @@ struct tdt_ctx {
   uint16_t *packed;             // LDS-table image of the bound cells buffer
   const tdt_buffer *packed_of;  // which buffer/version `packed` was built from
   unsigned long long packed_version;
-  uint32_t *slot_cost, *slot_order, *order_hist;   // per queue slot: cost feedback of the last trace dispatch, the hand-out order derived from it; 2 x 256 sort counters
+  uint32_t *slot_cost, *slot_acc, *slot_order, *order_hist;   // per queue slot: cost feedback of the last trace dispatch, the hand-out order derived from it; 2 x 256 sort counters
   uint32_t cost_dispatches;            // dispatches summed into slot_cost so far
   uint32_t tile_capacity, cost_tiles;  // allocation size (work-groups); number of work-groups slot_cost holds the last dispatch's costs for (0: none)
   unsigned char cost_sig[256];         // what those costs were measured on (camera, octree parameters, buffer versions, partition)
@@ -793,10 +859,12 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
       if (ctx->tile_capacity < (uint32_t)t.owned) {
         if (ctx->slot_cost) (void)hipFree(ctx->slot_cost);
         if (ctx->slot_order) (void)hipFree(ctx->slot_order);
-        ctx->slot_cost = ctx->slot_order = nullptr; ctx->tile_capacity = 0; ctx->cost_tiles = 0;
+        if (ctx->slot_acc) (void)hipFree(ctx->slot_acc);
+        ctx->slot_cost = ctx->slot_order = ctx->slot_acc = nullptr; ctx->tile_capacity = 0; ctx->cost_tiles = 0;
         TDT_HIP(ctx, hipMalloc((void **)&ctx->slot_cost, (size_t)t.owned * 1024 * sizeof(uint32_t)));
         TDT_HIP(ctx, hipMalloc((void **)&ctx->slot_order, (size_t)t.owned * 1024 * sizeof(uint32_t)));
-        if (!ctx->order_hist) TDT_HIP(ctx, hipMalloc((void **)&ctx->order_hist, 1024 * sizeof(uint32_t)));
+        TDT_HIP(ctx, hipMalloc((void **)&ctx->slot_acc, (size_t)t.owned * 1024 * sizeof(uint32_t)));
+        if (!ctx->order_hist) TDT_HIP(ctx, hipMalloc((void **)&ctx->order_hist, 1028 * sizeof(uint32_t)));
         ctx->tile_capacity = (uint32_t)t.owned;
       }
       // what this dispatch traces: if it equals what the recorded costs were measured on (a still camera: progressive
@@ -825,9 +893,16 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
         const uint32_t n_slots = (uint32_t)t.owned * 1024u, n_chunks = (n_slots + tdt::kOrderChunk - 1) / tdt::kOrderChunk;
         const uint32_t og = tdt::kOrderBits;
         TDT_HIP(ctx, hipMemsetAsync(ctx->order_hist, 0, 1024 * sizeof(uint32_t), ctx->stream));
-        hipLaunchKernelGGL(tdt::order_hist_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, n_slots, ctx->order_hist, og, smooth);
-        hipLaunchKernelGGL(tdt::order_scatter_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, n_slots,
-                           ctx->order_hist, ctx->order_hist + 512, ctx->slot_order, og, smooth, keep_costs ? 0 : 1);
+        hipLaunchKernelGGL(tdt::order_hist_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, ctx->slot_acc, n_slots, ctx->order_hist, og, smooth, keep_costs ? 1 : 0);
+        {
+          static const float max_share = getenv("TDT_MAX_SHARE") ? (float)atof(getenv("TDT_MAX_SHARE")) : 0.25f;
+          const uint32_t lanes = (uint32_t)ctx->num_cus * TDT_BLOCKS_PER_CU * TDT_BLOCK;
+          if (!smooth) hipLaunchKernelGGL(tdt::order_plan_kernel, dim3(1), dim3(512), 0, ctx->stream, ctx->order_hist, og, lanes, max_share, ctx->order_hist + 1024);
+          else TDT_HIP(ctx, hipMemsetAsync(ctx->order_hist + 1024, 0, sizeof(uint32_t), ctx->stream));
+          P.plan = ctx->order_hist + 1024;
+        }
+        hipLaunchKernelGGL(tdt::order_scatter_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, ctx->slot_acc, n_slots,
+                           ctx->order_hist, ctx->order_hist + 512, ctx->slot_order, og, smooth);
         TDT_HIP(ctx, hipGetLastError());
         P.slot_order = ctx->slot_order;
       } else {                                        // no usable history: image order, fresh cost array
@@ -867,6 +942,9 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     }
 #define TDT_LAUNCH(C) do { if (pow2) hipLaunchKernelGGL((tdt::trace_kernel<C, true>), grid, block, 0, ctx->stream, P); \
                            else hipLaunchKernelGGL((tdt::trace_kernel<C, false>), grid, block, 0, ctx->stream, P); } while (0)
+    if (!launched && counts_out && getenv("TDT_COUNT_SPECIALISED") && pow2 && safev && resident && P.max_depth == 6) {
+      hipLaunchKernelGGL((tdt::trace_kernel<true, true, 6, true, true>), grid, block, 0, ctx->stream, P); launched = true;   // diagnostics: region timers of the specialised form
+    }
     if (launched) {}
     else if (mode != 2 && !counts_out) TDT_LAUNCH(false);
     else if (mode != 2) TDT_LAUNCH(true);
@@ -899,7 +977,7 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
   if (!ctx) return fail(nullptr, TDT_ERR_HIP, "out of host memory");
   ctx->device = device_id;
   for (auto &s : ctx->ssbo) s = nullptr;
-  ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr; ctx->queue = nullptr; ctx->packed = nullptr; ctx->packed_of = nullptr; ctx->packed_version = 0; ctx->present = nullptr; ctx->present_bytes = 0; ctx->pixel_log = nullptr; ctx->pixel_log_u32 = 0; ctx->slot_cost = ctx->slot_order = ctx->order_hist = nullptr; ctx->tile_capacity = ctx->cost_tiles = 0; ctx->cost_dispatches = 0;
+  ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr; ctx->queue = nullptr; ctx->packed = nullptr; ctx->packed_of = nullptr; ctx->packed_version = 0; ctx->present = nullptr; ctx->present_bytes = 0; ctx->pixel_log = nullptr; ctx->pixel_log_u32 = 0; ctx->slot_cost = ctx->slot_acc = ctx->slot_order = ctx->order_hist = nullptr; ctx->tile_capacity = ctx->cost_tiles = 0; ctx->cost_dispatches = 0;
   { const char *nc = getenv("TDT_NO_COST_ORDER"); ctx->no_cost_order = nc && nc[0] == '1'; }
   ctx->scan = nullptr; ctx->max_parent_value = ctx->max_any_value = 0xFFFFFFFFu;
   { hipDeviceProp_t prop; ctx->num_cus = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
@@ -930,6 +1008,7 @@ void tdt_ctx_destroy(tdt_ctx *ctx) {
   if (ctx->scan) (void)hipFree(ctx->scan);
   if (ctx->slot_cost) (void)hipFree(ctx->slot_cost);
   if (ctx->slot_order) (void)hipFree(ctx->slot_order);
+  if (ctx->slot_acc) (void)hipFree(ctx->slot_acc);
   if (ctx->order_hist) (void)hipFree(ctx->order_hist);
   if (ctx->pixel_log) (void)hipFree(ctx->pixel_log);
   if (ctx->present) (void)hipFree(ctx->present);

@@ -277,6 +277,7 @@ class ComputeShader:
         self.ctx.check(lib().tdt_debug_counters(self.ctx.h, c))
         d = dict(zip(self.DEBUG_FIELDS, [int(v) for v in c[8:18]]))
         d.update(first_start=int(c[18]), last_end=int(c[19]), sum_wave_cycles=int(c[20]), waves=int(c[21]), queue_empty=int(c[22]))
+        d["region_cycles"] = dict(zip(("traverse", "gate", "hit_scatter", "end", "fetch", "primary", "newray"), [int(v) for v in c[24:31]]))
         return d
 
     def debug_wave_ends(self, n):

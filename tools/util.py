@@ -14,3 +14,6 @@ print(json.dumps(c)); print(json.dumps(d))
 for k in ("trav", "level", "event", "scatter"):
     print(f"{k:8s} util {d[k+'_active']/max(1,d[k+'_slots']):.3f}  slots {d[k+'_slots']:.4g}")
 print("levels/iter %.2f  memo miss rate %.3f  iters/ray %.2f  rays/sample %.2f" % (c["node_loads"]/c["iterations"], d["memo_miss"]/c["node_loads"], c["iterations"]/c["octree_hit_calls"], c["octree_hit_calls"]/(c["pixels"]*spp)))
+rc = d.get("region_cycles", {})
+tot = sum(rc.values()) or 1
+print("time per region (wave cycles, instrumented build):", "  ".join(f"{k} {100*v/tot:.1f}%" for k, v in rc.items()))
