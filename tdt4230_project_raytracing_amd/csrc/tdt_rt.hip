@@ -204,6 +204,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     if (COUNT) lane_E += (state != ST_TRAVERSE && state != ST_DONE) ? 1u : 0u;
     if (state == ST_HIT) {                            // RayColor loop body rc:272-295
       if (COUNT) { cnt.scatter_slots += slot64(); cnt.scatter_active++; }
+      const MatRef mat = material_fetch(P, hit_index);
       if (leaf_rec) { cube_hit_record(r, t_stride, leaf_box_x, leaf_box_y, leaf_box_z, inv_pow_depth, pc.leaf); if (COUNT) cnt.leaf_records++; }
       loop_count += 1;
       const HitTmp &src = use_leaf ? pc.leaf : pc.root;
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       h.px = src.px; h.py = src.py; h.pz = src.pz; h.nx = src.nx; h.ny = src.ny; h.nz = src.nz; h.ff = src.ff;
       h.index = hit_index;
       Ray nr; float tr, tg, tb;
-      if (scatter<COUNT>(P, r, h, nr, tr, tg, tb, cnt)) {
+      if (scatter<COUNT>(P, r, h, mat, nr, tr, tg, tb, cnt)) {
         ar = ar * tr; ag = ag * tg; ab = ab * tb;
         r = nr;
         state = ST_NEWRAY;

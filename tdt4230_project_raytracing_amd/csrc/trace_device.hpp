@@ -441,23 +441,31 @@ TDT_DEV float rand2(float cx, float cy) {   // Rand(vec2) rc:53
   return f_fract(sin_poly(cy * 78.233f + cx * 12.9898f) * 43758.5453f);
 }
 
-TDT_DEV void load_albedo(const TraceParams &P, uint32_t mo, float &ar, float &ag, float &ab) {   // AlbedoColor rc:309-313
-  uint32_t ai = ld_dw(P.materials, P.materials_dwords, mo + 8u) * 12u;
-  ar = __uint_as_float(ld_dw(P.albedos, P.albedos_dwords, ai));
-  ag = __uint_as_float(ld_dw(P.albedos, P.albedos_dwords, ai + 4u));
-  ab = __uint_as_float(ld_dw(P.albedos, P.albedos_dwords, ai + 8u));
+// materials[hit.index] (rc:189-196): the three dwords are fetched together, and as early as the hit is known, so that the
+// round trip overlaps the hit record's arithmetic instead of standing in front of the material switch
+struct MatRef { uint32_t type, attribute, albedo; };
+TDT_DEV MatRef material_fetch(const TraceParams &P, uint32_t index) {
+  const uint32_t mo = index * 12u;
+  MatRef m;
+  m.type = ld_dw(P.materials, P.materials_dwords, mo);
+  m.attribute = ld_dw(P.materials, P.materials_dwords, mo + 4u);
+  m.albedo = ld_dw(P.materials, P.materials_dwords, mo + 8u);
+  return m;
 }
 
 // switch (materials[hit.index].type) rc:278-291; returns false when the path ends
 template <bool COUNT>
-TDT_DEV bool scatter(const TraceParams &P, const Ray &r, const Hit &h, Ray &out, float &ar, float &ag, float &ab, Counters &cnt) {
-  uint32_t mo = h.index * 12u;
-  int32_t type = (int32_t)ld_dw(P.materials, P.materials_dwords, mo);
+TDT_DEV bool scatter(const TraceParams &P, const Ray &r, const Hit &h, const MatRef &mat, Ray &out, float &ar, float &ag, float &ab, Counters &cnt) {
+  const int32_t type = (int32_t)mat.type;
+  // the second-level reads (albedo; fuzz or index of refraction) are issued at the top of each branch and used at its end
+  const uint32_t ai = mat.albedo * 12u;
   float dx = r.dx, dy = r.dy, dz = r.dz;
   float nx = h.nx, ny = h.ny, nz = h.nz;
   out.ox = h.px; out.oy = h.py; out.oz = h.pz;
   if (COUNT) { cnt.lambertian += (type == 0); cnt.metal += (type == 1); cnt.dielectric += (type == 2); cnt.unknown += ((uint32_t)type > 2u); }
   if (type == 0) {   // ScatterLambertian rc:470-482, constructFrisvad rc:453-468, SampleGGXVNDF rc:27-49
+    const float alb_r = __uint_as_float(ld_dw(P.albedos, P.albedos_dwords, ai)), alb_g = __uint_as_float(ld_dw(P.albedos, P.albedos_dwords, ai + 4u)),
+                alb_b = __uint_as_float(ld_dw(P.albedos, P.albedos_dwords, ai + 8u));
     float rs = q_rsq((nz * nz + ny * ny) + nx * nx);
     float mx = nx * rs, my = ny * rs, mz = nz * rs;
     bool sing = nz < -0.9999f;
@@ -510,16 +518,18 @@ TDT_DEV bool scatter(const TraceParams &P, const Ray &r, const Hit &h, Ray &out,
     float qx = nx + (dx + -(dt * ex)), qy = ny + (dy + -(dt * ey)), qz = nz + (dz + -(dt * ez));
     rs = q_rsq((qz * qz + qy * qy) + qx * qx);
     out.dx = qx * rs; out.dy = qy * rs; out.dz = qz * rs;
-    load_albedo(P, mo, ar, ag, ab);
+    ar = alb_r; ag = alb_g; ab = alb_b;
     return true;
   }
   if (type == 1) {   // ScatterMetal rc:484-491, RandInHemisphere rc:106-115 (one cube sample, as compiled)
+    const float alb_r = __uint_as_float(ld_dw(P.albedos, P.albedos_dwords, ai)), alb_g = __uint_as_float(ld_dw(P.albedos, P.albedos_dwords, ai + 4u)),
+                alb_b = __uint_as_float(ld_dw(P.albedos, P.albedos_dwords, ai + 8u));
+    const float m_fuzz = __uint_as_float(ld_dw(P.metal, P.metal_dwords, mat.attribute << 2));
     float rs = q_rsq((nz * nz + ny * ny) + nx * nx);
     float mx = nx * rs, my = ny * rs, mz = nz * rs;
     float dt = ((mz * dz + my * dy) + mx * dx) * 2.0f;
     float rx = dx + -(dt * mx), ry = dy + -(dt * my), rz = dz + -(dt * mz);
-    uint32_t at = ld_dw(P.materials, P.materials_dwords, mo + 4u);
-    float fuzz = __uint_as_float(ld_dw(P.metal, P.metal_dwords, at << 2));
+    const float fuzz = m_fuzz;
     float hx = -1.0f + 2.0f * rand2(h.px, h.py);
     float hy = -1.0f + 2.0f * rand2(h.px + hx, h.py + hx);
     float hz = -1.0f + 2.0f * rand2(h.px + hy, h.py + hy);
@@ -529,12 +539,11 @@ TDT_DEV bool scatter(const TraceParams &P, const Ray &r, const Hit &h, Ray &out,
     rs = q_rsq((qz * qz + qy * qy) + qx * qx);
     qx = qx * rs; qy = qy * rs; qz = qz * rs;
     out.dx = qx; out.dy = qy; out.dz = qz;
-    load_albedo(P, mo, ar, ag, ab);
+    ar = alb_r; ag = alb_g; ab = alb_b;
     return -(qz * nz + qy * ny) < qx * nx;
   }
   if (type == 2) {   // ScatterDielectric rc:499-522, reflectance rc:494-497
-    uint32_t at = ld_dw(P.materials, P.materials_dwords, mo + 4u);
-    float ir = __uint_as_float(ld_dw(P.dielectric, P.dielectric_dwords, at << 2));
+    const float ir = __uint_as_float(ld_dw(P.dielectric, P.dielectric_dwords, mat.attribute << 2));
     float ratio = h.ff ? q_rcp(ir) : ir;
     float pz_ = dz * nz, py_ = dy * ny, px_ = dx * nx;
     float cos_t = f_min((-pz_ + -py_) + -px_, 1.0f);
