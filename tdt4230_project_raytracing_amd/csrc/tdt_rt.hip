@@ -697,6 +697,7 @@ struct tdt_ctx {
   int num_cus;
   bool force_generic;   // TDT_FORCE_GENERIC=1: always run the literal-arithmetic kernel (A/B testing)
   int event_threshold;  // TDT_EVENT_THRESHOLD=n fixes the event threshold (experiments); 0 = adaptive
+  int force_smooth; bool no_cost_accum; float max_share;   // TDT_ORDER_SMOOTH / TDT_NO_COST_ACCUM / TDT_MAX_SHARE (diagnostics)
   float event_k;        // TDT_EVENT_K overrides the adaptive threshold's r (0: chosen from the tree size)
   uint32_t *present; size_t present_bytes;   // staging of tdt_image_read_rgba8
   uint32_t *pixel_log; size_t pixel_log_u32;   // TDT_PIXEL_LOG diagnostics (instrumented dispatches only)
@@ -884,19 +885,17 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
       }
       P.slot_cost = ctx->slot_cost;
       if (ctx->cost_tiles == (uint32_t)t.owned) {
-        static const int force_smooth = getenv("TDT_ORDER_SMOOTH") ? atoi(getenv("TDT_ORDER_SMOOTH")) : -1;
-        const int smooth = force_smooth >= 0 ? force_smooth : (std::memcmp(sig, ctx->cost_sig, sizeof sig) != 0 ? 1 : 0);
+        const int smooth = ctx->force_smooth >= 0 ? ctx->force_smooth : (std::memcmp(sig, ctx->cost_sig, sizeof sig) != 0 ? 1 : 0);
         // same inputs again (progressive passes, repeated frames): keep adding to the costs — every pass sharpens the
         // estimate of what a pixel costs; otherwise start over
-        static const bool no_accum = getenv("TDT_NO_COST_ACCUM") != nullptr;
-        const bool keep_costs = !smooth && !no_accum && ctx->cost_dispatches < 256;   // (restart before the sums can saturate)
+        const bool keep_costs = !smooth && !ctx->no_cost_accum && ctx->cost_dispatches < 256;   // (restart before the sums can saturate)
         ctx->cost_dispatches = keep_costs ? ctx->cost_dispatches + 1 : 0;
         const uint32_t n_slots = (uint32_t)t.owned * 1024u, n_chunks = (n_slots + tdt::kOrderChunk - 1) / tdt::kOrderChunk;
         const uint32_t og = tdt::kOrderBits;
         TDT_HIP(ctx, hipMemsetAsync(ctx->order_hist, 0, 1024 * sizeof(uint32_t), ctx->stream));
         hipLaunchKernelGGL(tdt::order_hist_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, ctx->slot_acc, n_slots, ctx->order_hist, og, smooth, keep_costs ? 1 : 0);
         {
-          static const float max_share = getenv("TDT_MAX_SHARE") ? (float)atof(getenv("TDT_MAX_SHARE")) : 0.25f;
+          const float max_share = ctx->max_share;
           const uint32_t lanes = (uint32_t)ctx->num_cus * TDT_BLOCKS_PER_CU * TDT_BLOCK;
           if (!smooth) hipLaunchKernelGGL(tdt::order_plan_kernel, dim3(1), dim3(512), 0, ctx->stream, ctx->order_hist, og, lanes, max_share, ctx->order_hist + 1024);
           else TDT_HIP(ctx, hipMemsetAsync(ctx->order_hist + 1024, 0, sizeof(uint32_t), ctx->stream));
@@ -979,7 +978,10 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
   ctx->device = device_id;
   for (auto &s : ctx->ssbo) s = nullptr;
   ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr; ctx->queue = nullptr; ctx->packed = nullptr; ctx->packed_of = nullptr; ctx->packed_version = 0; ctx->present = nullptr; ctx->present_bytes = 0; ctx->pixel_log = nullptr; ctx->pixel_log_u32 = 0; ctx->slot_cost = ctx->slot_acc = ctx->slot_order = ctx->order_hist = nullptr; ctx->tile_capacity = ctx->cost_tiles = 0; ctx->cost_dispatches = 0;
-  { const char *nc = getenv("TDT_NO_COST_ORDER"); ctx->no_cost_order = nc && nc[0] == '1'; }
+  { const char *nc = getenv("TDT_NO_COST_ORDER"); ctx->no_cost_order = nc && nc[0] == '1';
+    const char *fs = getenv("TDT_ORDER_SMOOTH"); ctx->force_smooth = fs ? atoi(fs) : -1;
+    ctx->no_cost_accum = getenv("TDT_NO_COST_ACCUM") != nullptr;
+    const char *ms = getenv("TDT_MAX_SHARE"); ctx->max_share = ms ? (float)atof(ms) : 0.25f; }
   ctx->scan = nullptr; ctx->max_parent_value = ctx->max_any_value = 0xFFFFFFFFu;
   { hipDeviceProp_t prop; ctx->num_cus = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
   { const char *fg = getenv("TDT_FORCE_GENERIC"); ctx->force_generic = fg && fg[0] == '1';

@@ -194,6 +194,21 @@ def test_cost_feedback_order_changes_only_the_schedule(oracle, monkeypatch, cfg)
         r.close()
 
 
+@pytest.mark.parametrize("env", [("TDT_ORDER_SMOOTH", "1"), ("TDT_MAX_SHARE", "0"), ("TDT_MAX_SHARE", "100"), ("TDT_NO_COST_ACCUM", "1")])
+def test_every_scheduling_variant_is_the_same_bits(oracle, monkeypatch, env):
+    """Tile-sum order, exact / batched queue draws, costs from the last dispatch only: schedules, not arithmetic."""
+    monkeypatch.setenv(*env)
+    scene = host.Scene.config(3)
+    cam = host.camera_reference_pose(256, 160, 3, 8)
+    ref = oracle.render(scene, cam, threads=8)
+    r = rt.Renderer(scene, cam)
+    try:
+        for _ in range(3):
+            assert _eq(r.render(), ref)
+    finally:
+        r.close()
+
+
 def test_cost_feedback_after_the_camera_moved(oracle):
     """When the inputs of a dispatch differ from what the recorded costs were measured on (camera moved, scene edited),
     8x8 tiles are ordered by their summed cost instead of single pixels; a repeat of the same view then goes back to
