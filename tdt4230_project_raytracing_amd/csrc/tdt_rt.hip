@@ -79,9 +79,9 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   if (threadIdx.x < 16 && P.lds_nodes + threadIdx.x < ((P.lds_nodes + 7u) & ~7u) + 8u)
     s_nodes[P.lds_nodes + threadIdx.x] = (uint16_t)((RESIDENT && POW2) ? 0u : kPackedEscape);
   __syncthreads();
-  __shared__ uint32_t s_grid[512];
+  constexpr bool kUseGrid = !COUNT && POW2 && SAFEV && DEPTH >= kGridLevels;   // see build_top_grid
+  __shared__ uint32_t s_grid[kUseGrid ? kGridEntries : 1];
   __shared__ int s_grid_ok;
-  constexpr bool kUseGrid = !COUNT && POW2 && SAFEV && !RESIDENT && DEPTH >= 3;   // see build_top_grid
   if (kUseGrid) build_top_grid(s_nodes, P.lds_nodes, DEPTH, s_grid, &s_grid_ok);
   NodeSource ns;
   ns.lds = s_nodes; ns.lds_nodes = P.lds_nodes; ns.lds_cells = (P.lds_nodes + 7u) >> 3;
@@ -441,17 +441,18 @@ __global__ __launch_bounds__(256) void selftest_kernel(int which, unsigned long 
     if (k > 0 && i < stride) break;                   // wrapped
     const float x = __uint_as_float(i);
     if (which == 5 || which == 6) {
-      // build_top_grid's claim, for EVERY coordinate c in [0,1) and every cell index v < 128: outside the bands
-      // (|8c - rint(8c)| > kGridBand) the x decision of levels 1..3 is the plain binary digit of c and never 2v+2.
-      // which == 6 checks the harness: with the band test removed the claim must fail.
+      // build_top_grid's claim, for EVERY coordinate c in [0,1) and every cell index below grid_v_bound: outside the
+      // bands (|2^L c - rint(2^L c)| > kGridBand) the x decision of levels 1..L is the plain binary digit of c and never
+      // 2v+2.  which == 6 checks the harness: with the band test removed the claim must fail.
       if (!(x >= 0.0f && x < 1.0f)) continue;
-      const float t8 = x * 8.0f;
-      if (which == 5 && !(__builtin_fabsf(t8 - __builtin_rintf(t8)) > kGridBand)) continue;
-      const uint32_t x3 = (uint32_t)t8;
-      for (int l = 1; l <= 3; l++) {
+      const float tg = x * (float)(1 << kGridLevels);
+      if (which == 5 && !(__builtin_fabsf(tg - __builtin_rintf(tg)) > kGridBand)) continue;
+      const uint32_t xg = (uint32_t)tg;
+      for (int l = 1; l <= kGridLevels; l++) {
         const float f = l == 1 ? x : f_fract_nonneg(x * (float)(1 << (l - 1)));
-        const uint32_t digit = (x3 >> (3 - l)) & 1u;
-        for (uint32_t v = 0; v < 128u; v++) {
+        const uint32_t digit = (xg >> (kGridLevels - l)) & 1u;
+        const uint32_t vmax = l == 1 ? 1u : grid_v_bound(l - 1);          // the cell index this level's decision uses
+        for (uint32_t v = 0; v < vmax; v++) {
           const float fv = (float)v, q = (fv + f) - fv;
           const uint32_t qa = q > 0.5f ? 1u : 0u, qb = q == 1.0f ? 1u : 0u;
           bad += (qa != digit || qb != 0u) ? 1u : 0u;

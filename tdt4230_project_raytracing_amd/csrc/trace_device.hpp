@@ -152,7 +152,7 @@ struct NodeSource {
   const uint16_t *lds;                                // LDS table
   uint32_t lds_nodes;                                 // valid entries
   uint32_t lds_cells;                                 // cells they make up (the last may be partial): index of the sentinel cell
-  const uint32_t *grid;                               // top-3-level jump table (see build_top_grid), or unusable when !grid_ok
+  const uint32_t *grid;                               // top-level jump table (see build_top_grid), or unusable when !grid_ok
   bool grid_ok;
   __amdgpu_buffer_rsrc_t cells;                       // raw buffer over the cells payload (8-byte granules)
 };
@@ -263,35 +263,42 @@ TDT_DEV bool tree_lookup(const TraceParams &P, const NodeSource &ns, float cx, f
 // key = node index (29 bits) | code << 30.
 template <int CL>
 struct NodeMemo { uint32_t key[CL]; uint32_t val[CL]; };
-// Top-3-level jump table.  The y and z child digits of treeLookup are exact integer digits (tree_lookup_pow2); the x
-// decision of a level is  a = fl(v + f) - v > 0.5  (and b = ... == 1), which for a cell index v < 128 differs from the
-// plain binary digit floor(2 f) only when f lies within ulp(v + f) <= 2^-17 above 1/2 or below 1.  So whenever 8 c_x is
-// farther than 2^-12 from an integer, the first three levels are a pure function of the top three digits of (x, y, z):
-// grid[x3 << 6 | y3 << 3 | z3] = value << 4 | levels << 2 | code of the node that descent reaches (it may stop at an
-// EMPTY / LEAF node after 1 or 2 levels).  One LDS read then replaces three dependent ones; lanes inside a band (about
-// 0.05 % of the steps) send their wave through the level-by-level form, so the result is the same bits either way.
-// Built per block from the LDS node table; unusable (grid_ok = false) when the tree is shallower than 3 levels, when a
-// top node is not LDS-resident, or when a top-level PARENT's cell index is >= 128 (a tree edited so that its top cells
-// were re-allocated — octree_update.comp can do that).  Used by the scene-specialised kernels of trees that do not fit the
-// LDS table (512^3: 195 -> 177 ms, 256^3: 360 -> 355 ms); for LDS-resident trees, whose levels are a ds_read_b128 and
-// 20 instructions each, it measured 4 % slower and is left out.
+// Top-level jump table (kGridLevels = 4 levels).  The y and z child digits of treeLookup are exact integer digits
+// (tree_lookup_pow2); the x decision of a level is  a = fl(v + f) - v > 0.5  (and b = ... == 1), which differs from the
+// plain binary digit floor(2 f) only when f lies within ulp(v + f) above 1/2 or below 1: <= 2^-17 for a cell index
+// v < 128, <= 2^-14 for v < 1024.  So whenever 16 c_x is farther than 2^-12 from an integer, the first four levels are a
+// pure function of the top four digits of (x, y, z):  grid[x4 << 8 | y4 << 4 | z4] = value << 5 | levels << 2 | code of the
+// node that descent reaches (it may stop at an EMPTY / LEAF node earlier).  One LDS read then replaces four dependent
+// ones; lanes inside a band (about 0.05 % of the steps) send their wave through the level-by-level form, so the result
+// is the same bits either way.  Built per block from the LDS node table; unusable (grid_ok = false) when the tree is
+// shallower than 4 levels, when a top node is not LDS-resident, or when a PARENT of levels 1-2 points at a cell index
+// >= 128 or one of level 3 at >= 1024 (a tree edited so that its top cells were re-allocated — octree_update.comp can do
+// that).  Used by all scene-specialised kernels of depth >= 4 (4K/256^3: 321 -> 297 ms, 1080p/512^3: 177 -> 165 ms,
+// 64^3: 33.9 -> 33.3 ms; a 3-level table was 4 % SLOWER on the LDS-resident 64^3 tree, whose levels are a ds_read_b128 and
+// 20 instructions each).
+constexpr int kGridLevels = 4;
+constexpr uint32_t kGridEntries = 1u << (3 * kGridLevels);
 constexpr float kGridBand = 0x1.0p-12f;
+TDT_DEV uint32_t grid_v_bound(int level) { return level < 3 ? 128u : 1024u; }   // bound on the cell index a level-`level` PARENT may hold
 TDT_DEV void build_top_grid(const uint16_t *lds, uint32_t lds_nodes, int depth, uint32_t *grid, int *grid_ok) {
-  if (threadIdx.x == 0) *grid_ok = depth >= 3 ? 1 : 0;
+  if (threadIdx.x == 0) *grid_ok = depth >= kGridLevels ? 1 : 0;
   __syncthreads();
-  if (threadIdx.x < 512 && depth >= 3) {
-    const uint32_t x3 = threadIdx.x >> 6, y3 = (threadIdx.x >> 3) & 7u, z3 = threadIdx.x & 7u;
-    uint32_t v = 0, code = 1u, m = 0;
-    bool ok = true;
-    for (int l = 1; l <= 3 && code == 1u; l++) {
-      const uint32_t idx = ((2u * v + ((x3 >> (3 - l)) & 1u)) << 2) + (((y3 >> (3 - l)) & 1u) << 1) + ((z3 >> (3 - l)) & 1u);
-      const uint32_t n = lds[idx < lds_nodes ? idx : lds_nodes];
-      if (n == kPackedEscape) { ok = false; break; }
-      v = n >> 2; code = n & 3u; m = (uint32_t)l;
-      if (code == 1u && l < 3 && v >= 128u) ok = false;     // this v feeds the next level's x decision
+  if (depth >= kGridLevels) {
+    for (uint32_t e = threadIdx.x; e < kGridEntries; e += blockDim.x) {
+      const uint32_t xg = e >> (2 * kGridLevels), yg = (e >> kGridLevels) & ((1u << kGridLevels) - 1u), zg = e & ((1u << kGridLevels) - 1u);
+      uint32_t v = 0, code = 1u, m = 0;
+      bool ok = true;
+      for (int l = 1; l <= kGridLevels && code == 1u; l++) {
+        const int sh = kGridLevels - l;
+        const uint32_t idx = ((2u * v + ((xg >> sh) & 1u)) << 2) + (((yg >> sh) & 1u) << 1) + ((zg >> sh) & 1u);
+        const uint32_t n = lds[idx < lds_nodes ? idx : lds_nodes];
+        if (n == kPackedEscape) { ok = false; break; }
+        v = n >> 2; code = n & 3u; m = (uint32_t)l;
+        if (code == 1u && l < kGridLevels && v >= grid_v_bound(l)) ok = false;     // this v feeds the next level's x decision
+      }
+      grid[e] = (v << 5) | (m << 2) | code;
+      if (!ok) atomicAnd(grid_ok, 0);
     }
-    grid[threadIdx.x] = (v << 4) | (m << 2) | code;
-    if (!ok) atomicAnd(grid_ok, 0);
   }
   __syncthreads();
 }
@@ -335,16 +342,16 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
   uint32_t qx = 1u, v = 0, code = 1u;                 // qx: x digits below a sentinel bit that counts the levels visited
   const float fx0 = fx;
   bool jumped = false;
-  if (!COUNT && !RESIDENT && DEPTH >= 3 && ns.grid_ok) {   // levels 1..3 in one step (see build_top_grid)
-    const float t8 = fx0 * 8.0f;                       // exact
-    const bool safe = __builtin_fabsf(t8 - __builtin_rintf(t8)) > kGridBand;
+  if (!COUNT && DEPTH >= kGridLevels && ns.grid_ok) {   // the top levels in one step (see build_top_grid)
+    const float tg = fx0 * (float)(1 << kGridLevels);  // exact
+    const bool safe = __builtin_fabsf(tg - __builtin_rintf(tg)) > kGridBand;
     if (__builtin_expect(__ballot(!safe) == 0ull, 1)) {
-      const uint32_t x3 = (uint32_t)t8;               // floor: t8 in [0, 8)
-      const uint32_t g = ns.grid[(x3 << 6) | ((Yi >> (depth - 3)) << 3) | (Zi >> (depth - 3))];
-      const uint32_t m3 = (g >> 2) & 3u;
-      code = g & 3u; v = g >> 4;
-      qx = (1u << m3) | (x3 >> (3u - m3));
-      fx = f_fract_nonneg(t8);                        // fract(c * 2^3): level 4's coordinate (only used when code == 1, i.e. m3 == 3)
+      const uint32_t xg = (uint32_t)tg;               // floor: tg in [0, 2^kGridLevels)
+      const uint32_t g = ns.grid[(xg << (2 * kGridLevels)) | ((Yi >> (depth - kGridLevels)) << kGridLevels) | (Zi >> (depth - kGridLevels))];
+      const uint32_t mg = (g >> 2) & 7u;
+      code = g & 3u; v = g >> 5;
+      qx = (1u << mg) | (xg >> ((uint32_t)kGridLevels - mg));
+      fx = f_fract_nonneg(tg);                        // fract(c * 2^kGridLevels): the next level's coordinate (only used when code == 1)
       jumped = true;
     }
   }
@@ -423,7 +430,7 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
   }
 #pragma unroll
   for (int l = kMemoFirst + 1; l <= kMemoFirst + CL; l++) {
-    if (code == 1u && l <= depth) level(l, &memo.key[l - kMemoFirst - 1], &memo.val[l - kMemoFirst - 1]);
+    if (code == 1u && l <= depth && !(jumped && l <= kGridLevels)) level(l, &memo.key[l - kMemoFirst - 1], &memo.val[l - kMemoFirst - 1]);
   }
   for (int l = kMemoFirst + CL + 1; code == 1u && l <= depth; l++) level(l, nullptr, nullptr);
   const int m = 31 - __builtin_clz(qx);               // levels visited
