@@ -337,7 +337,8 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     w_rays += (uint32_t)__popcll(__ballot(state == ST_NEWRAY));
     if (P.event_threshold <= 0) {
       if (w_rays > kEventWindow) { w_steps >>= 1; w_rays >>= 1; }   // sliding window: the mix of pixels a wave sees changes over a frame
-      const float est = 64.0f / (0.5f + __builtin_sqrtf(P.event_k * (float)w_steps / ((float)w_rays + 1.0f)));
+      // (a schedule, not arithmetic of the image: the raw hardware rcp / sqrt do, 3 instructions instead of ~35)
+      const float est = 64.0f * __builtin_amdgcn_rcpf(0.5f + __builtin_amdgcn_sqrtf(P.event_k * (float)w_steps * __builtin_amdgcn_rcpf((float)w_rays + 1.0f)));
       const int th = (int)est;
       threshold = w_rays < 256u ? 24 : (th < 2 ? 2 : (th > 40 ? 40 : th));
     }
