@@ -33,6 +33,9 @@ TDT_DEV float f_rsq(float x) { return 1.0f / __builtin_sqrtf(x); }          // t
 TDT_DEV bool exp_in_window(float x) {      // biased exponent in [27, 228): |x| in [2^-100, 2^101)
   return ((__float_as_uint(x) & 0x7FFFFFFFu) - 0x0D800000u) < 0x65000000u;
 }
+TDT_DEV bool pos_in_window(float x) {      // x > 0 and in the window, in one unsigned compare (negative floats wrap past it)
+  return (__float_as_uint(x) - 0x0D800000u) < 0x65000000u;
+}
 TDT_DEV float rcp_core(float y) {          // RN(1/y) for y in the window
   const float r = __builtin_amdgcn_rcpf(y);
   const float e = __builtin_fmaf(-y, r, 1.0f);
@@ -52,11 +55,11 @@ TDT_DEV void q_rcp3(float a, float b, float c, float &ra, float &rb, float &rc) 
   } else { ra = rcp_core(a); rb = rcp_core(b); rc = rcp_core(c); }
 }
 TDT_DEV float q_sqrt(float x) {
-  if (__builtin_expect(__ballot(!(exp_in_window(x) && x > 0.0f)) != 0ull, 0)) return __builtin_sqrtf(x);
+  if (__builtin_expect(__ballot(!pos_in_window(x)) != 0ull, 0)) return __builtin_sqrtf(x);
   return sqrt_core(x);
 }
 TDT_DEV float q_rsq(float x) {             // RN(1 / RN(sqrt(x))): sqrt of a window value stays in the window
-  if (__builtin_expect(__ballot(!(exp_in_window(x) && x > 0.0f)) != 0ull, 0)) return 1.0f / __builtin_sqrtf(x);
+  if (__builtin_expect(__ballot(!pos_in_window(x)) != 0ull, 0)) return 1.0f / __builtin_sqrtf(x);
   return rcp_core(sqrt_core(x));
 }
 // min/max where a NaN operand yields the other operand (and ties return b)
