@@ -279,6 +279,11 @@ struct NodeMemo { uint32_t key[CL]; uint32_t val[CL]; };
 // that).  Used by all scene-specialised kernels of depth >= 4 (4K/256^3: 321 -> 297 ms, 1080p/512^3: 177 -> 165 ms,
 // 64^3: 33.9 -> 33.3 ms; a 3-level table was 4 % SLOWER on the LDS-resident 64^3 tree, whose levels are a ds_read_b128 and
 // 20 instructions each).
+// Trees that do not fit the LDS table: a node read at level >= kNoProbeFrom skips the table and goes to the memo / HBM path
+// directly.  The table holds the first 5120 cells of the breadth-first array, i.e. depths 0-4 and the start of depth 5, so a
+// probe for a node of a depth >= 5 cell almost never hits; it is only a cache, so skipping it is always correct
+// (4K/256^3: 292 -> 280 ms, 1080p/512^3: 166 -> 153 ms; from level 5 on: 286 / 154 ms).
+constexpr int kNoProbeFrom = 6;
 constexpr int kGridLevels = 4;
 constexpr uint32_t kGridEntries = 1u << (3 * kGridLevels);
 constexpr float kGridBand = 0x1.0p-12f;
@@ -407,10 +412,13 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
     // LDS table first: an unconditional read of min(idx, lds_nodes).  The slot just past the table holds
     // a sentinel: EMPTY (0) when the whole buffer is resident — a read past the end of the buffer IS 0
     // (robust access) — and the escape code otherwise, which sends the lane to the range-checked HBM path.
-    const uint32_t li = idx < ns.lds_nodes ? idx : ns.lds_nodes;
-    const uint32_t n = ns.lds[li];
-    const bool resident = RESIDENT || (n != kPackedEscape);
-    v = n >> 2; code = n & 3u;
+    bool resident = false;
+    if (RESIDENT || l < kNoProbeFrom) {
+      const uint32_t li = idx < ns.lds_nodes ? idx : ns.lds_nodes;
+      const uint32_t n = ns.lds[li];
+      resident = RESIDENT || (n != kPackedEscape);
+      v = n >> 2; code = n & 3u;
+    }
     if (!resident) {
       if (mkey && (*mkey & 0x1FFFFFFFu) == idx) {
         v = *mval; code = *mkey >> 30;
