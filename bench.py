@@ -118,8 +118,17 @@ def main():
 
     ev_pairs = []
 
+    first_pair = []
+
     def step(timed):
         with torch.cuda.stream(stream):
+            if not timed and not first_pair:             # the context's very first dispatch: image order, no cost history
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                first_pair.extend([e0, e1])
+                timed_first = True
+            else:
+                timed_first = False
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
@@ -131,6 +140,8 @@ def main():
             if timed:
                 e1.record(stream)
                 ev_pairs.append((e0, e1))
+            if timed_first:
+                first_pair[1].record(stream)
             if carry is not None:
                 for k in range(1, args.passes):
                     r.shader.dispatch_accumulate(dw, dh, 1, k * spp, spp, carry.data_ptr())
@@ -238,7 +249,9 @@ def main():
                        "schedule": "global pixel queue; pixels handed out most-expensive-first from the work counts (tree levels, "
                                    "steps, path events) the previous dispatch recorded per pixel (a bench step repeats the same frame; "
                                    "when the camera or scene changed, 8x8 tiles are ordered instead); the first dispatch of a "
-                                   "context runs in image order (TDT_NO_COST_ORDER=1: always)",
+                                   "context runs in image order (TDT_NO_COST_ORDER=1: always) — first_dispatch_ms is that dispatch, timed "
+                                   "during warm-up",
+                       "first_dispatch_ms": round(first_pair[0].elapsed_time(first_pair[1]), 4) if first_pair else None,
                        "partition": f"32x32 work-groups dealt round-robin over {world} rank(s)" + ("; one RCCL gather + de-interleave per step" if sharded else "")},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
