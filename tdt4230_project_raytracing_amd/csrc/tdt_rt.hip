@@ -307,7 +307,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
               n_pixels++;
               sr = 0.f; sg = 0.f; sb = 0.f; s = P.spp_begin;
               pc.root = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}; pc.leaf = pc.root; pc.root_t = 0.f;
-              if (P.accumulate) {
+              if (P.accumulate && P.spp_begin != 0) {    // (a range that starts at sample 0 starts from nothing)
                 const float4 acc = *(reinterpret_cast<const float4 *>(P.image) + pix);
                 sr = acc.x; sg = acc.y; sb = acc.z;
                 if (P.carry) {
@@ -701,6 +701,8 @@ struct tdt_ctx {
   int event_threshold;  // TDT_EVENT_THRESHOLD=n fixes the event threshold (experiments); 0 = adaptive
   int force_smooth; bool no_cost_accum; float max_share;   // TDT_ORDER_SMOOTH / TDT_NO_COST_ACCUM / TDT_MAX_SHARE (diagnostics)
   float event_k;        // TDT_EVENT_K overrides the adaptive threshold's r (0: chosen from the tree size)
+  void *frame_carry; size_t frame_carry_bytes;   // hit-record carry between the two phases of a frame (tdt_dispatch_compute)
+  bool no_two_phase;                             // TDT_NO_TWO_PHASE=1
   uint32_t *present; size_t present_bytes;   // staging of tdt_image_read_rgba8
   uint32_t *pixel_log; size_t pixel_log_u32;   // TDT_PIXEL_LOG diagnostics (instrumented dispatches only)
   bool no_specialise;   // TDT_NO_SPECIALISE=1: never pick a scene-specialised kernel (A/B testing)
@@ -765,6 +767,20 @@ int64_t owned_pixels(const tdt_compute *c, const Cover &k) {
     n += (int64_t)(w > 32 ? 32 : w) * (h > 32 ? 32 : h);
   }
   return n;
+}
+
+// What a trace dispatch depends on besides the sample range: camera, octree parameters, buffer identities and versions,
+// partition, covered size — compared with what the recorded pixel costs were measured on (see launch()).
+void make_sig(const tdt_ctx *ctx, const tdt_compute *c, const Cover &k, const tdt_image *img, unsigned char *sig) {
+  float of[7]; int32_t oi[3];
+  std::memcpy(of, ctx->ssbo[TDT_SLOT_OCTREE_FLOATS]->shadow, sizeof of);
+  std::memcpy(oi, ctx->ssbo[TDT_SLOT_OCTREE_INTS]->shadow, sizeof oi);
+  std::memset(sig, 0, sizeof ctx->cost_sig);
+  size_t o = 0;
+  auto put = [&](const void *p, size_t n) { if (o + n <= sizeof ctx->cost_sig) { std::memcpy(sig + o, p, n); o += n; } };
+  put(&c->image_width, sizeof(int32_t) * 4); put(c->horizontal, sizeof(float) * 12); put(&c->part_rank, sizeof(int) * 2);
+  put(of, sizeof of); put(oi, sizeof oi); put(&k.cover_w, sizeof k.cover_w); put(&k.cover_h, sizeof k.cover_h); put(&img->w, sizeof img->w); put(&img->h, sizeof img->h);
+  for (int sl = 0; sl < kNumSlots; sl++) if (ctx->ssbo[sl]) { put(&ctx->ssbo[sl], sizeof(void *)); put(&ctx->ssbo[sl]->version, sizeof ctx->ssbo[sl]->version); }
 }
 
 int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_begin, int spp_count, void *carry,
@@ -877,14 +893,7 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
       // tiles are sorted by their summed cost — measured on a 60 fps walk, exact-order-of-a-stale-frame is no better
       // than image order (256^3: 3 % worse), the tile form keeps about half of the gain
       unsigned char sig[sizeof ctx->cost_sig];
-      std::memset(sig, 0, sizeof sig);
-      {
-        size_t o = 0;
-        auto put = [&](const void *p, size_t n) { if (o + n <= sizeof sig) { std::memcpy(sig + o, p, n); o += n; } };
-        put(&c->image_width, sizeof(int32_t) * 4); put(c->horizontal, sizeof(float) * 12); put(&c->part_rank, sizeof(int) * 2);
-        put(of, sizeof of); put(oi, sizeof oi); put(&k.cover_w, sizeof k.cover_w); put(&k.cover_h, sizeof k.cover_h); put(&img->w, sizeof img->w); put(&img->h, sizeof img->h);
-        for (int sl = 0; sl < kNumSlots; sl++) if (ctx->ssbo[sl]) { put(&ctx->ssbo[sl], sizeof(void *)); put(&ctx->ssbo[sl]->version, sizeof ctx->ssbo[sl]->version); }
-      }
+      make_sig(ctx, c, k, img, sig);
       P.slot_cost = ctx->slot_cost;
       if (ctx->cost_tiles == (uint32_t)t.owned) {
         const int smooth = ctx->force_smooth >= 0 ? ctx->force_smooth : (std::memcmp(sig, ctx->cost_sig, sizeof sig) != 0 ? 1 : 0);
@@ -979,10 +988,11 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
   if (!ctx) return fail(nullptr, TDT_ERR_HIP, "out of host memory");
   ctx->device = device_id;
   for (auto &s : ctx->ssbo) s = nullptr;
-  ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr; ctx->queue = nullptr; ctx->packed = nullptr; ctx->packed_of = nullptr; ctx->packed_version = 0; ctx->present = nullptr; ctx->present_bytes = 0; ctx->pixel_log = nullptr; ctx->pixel_log_u32 = 0; ctx->slot_cost = ctx->slot_acc = ctx->slot_order = ctx->order_hist = nullptr; ctx->tile_capacity = ctx->cost_tiles = 0; ctx->cost_dispatches = 0;
+  ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr; ctx->queue = nullptr; ctx->packed = nullptr; ctx->packed_of = nullptr; ctx->packed_version = 0; ctx->present = nullptr; ctx->present_bytes = 0; ctx->frame_carry = nullptr; ctx->frame_carry_bytes = 0; ctx->pixel_log = nullptr; ctx->pixel_log_u32 = 0; ctx->slot_cost = ctx->slot_acc = ctx->slot_order = ctx->order_hist = nullptr; ctx->tile_capacity = ctx->cost_tiles = 0; ctx->cost_dispatches = 0;
   { const char *nc = getenv("TDT_NO_COST_ORDER"); ctx->no_cost_order = nc && nc[0] == '1';
     const char *fs = getenv("TDT_ORDER_SMOOTH"); ctx->force_smooth = fs ? atoi(fs) : -1;
     ctx->no_cost_accum = getenv("TDT_NO_COST_ACCUM") != nullptr;
+    ctx->no_two_phase = getenv("TDT_NO_TWO_PHASE") != nullptr;
     const char *ms = getenv("TDT_MAX_SHARE"); ctx->max_share = ms ? (float)atof(ms) : 0.25f; }
   ctx->scan = nullptr; ctx->max_parent_value = ctx->max_any_value = 0xFFFFFFFFu;
   { hipDeviceProp_t prop; ctx->num_cus = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
@@ -1017,6 +1027,7 @@ void tdt_ctx_destroy(tdt_ctx *ctx) {
   if (ctx->order_hist) (void)hipFree(ctx->order_hist);
   if (ctx->pixel_log) (void)hipFree(ctx->pixel_log);
   if (ctx->present) (void)hipFree(ctx->present);
+  if (ctx->frame_carry) (void)hipFree(ctx->frame_carry);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1261,7 +1272,8 @@ int tdt_image_read_rgba8(tdt_image *img, int top_down, uint8_t *dst) {
   const size_t bytes = (size_t)img->w * img->h * 4;
   if (ctx->present_bytes < bytes) {
     if (ctx->present) (void)hipFree(ctx->present);
-    ctx->present = nullptr; ctx->present_bytes = 0;
+  if (ctx->frame_carry) (void)hipFree(ctx->frame_carry);
+    ctx->present = nullptr; ctx->present_bytes = 0; ctx->frame_carry = nullptr; ctx->frame_carry_bytes = 0;
     TDT_HIP(ctx, hipMalloc((void **)&ctx->present, bytes));
     ctx->present_bytes = bytes;
   }
@@ -1299,7 +1311,40 @@ static int launch_update(tdt_compute *c, int width, int height, int depth) {
 int tdt_dispatch_compute(tdt_compute *c, int width, int height, int depth) {
   if (!c) return TDT_ERR_INVALID_VALUE;
   if (c->kind == TDT_PROGRAM_OCTREE_UPDATE) return launch_update(c, width, height, depth);
-  return launch(c, width, height, depth, 0, 0, c->samples_per_pixel, nullptr, c->samples_per_pixel, nullptr);
+  // A frame whose inputs differ from what the recorded pixel costs were measured on (first frame, moved camera, edited
+  // scene) is traced in two phases: spp/16 probe samples per pixel in image (or tile-sum) order, then — the launch below
+  // sees identical inputs and fresh costs — the rest in the per-pixel cost order of THIS frame's probe, and a resolve.  Running
+  // sums and the hit-record carry go through HBM between the phases exactly as in progressive rendering, so the frame is the
+  // same bits as one pass (tests/test_gpu_fullsize.py).  Frames that repeat their inputs take one pass in the exact order.
+  tdt_ctx *ctx = c->ctx;
+  const int spp = c->samples_per_pixel;
+  bool ready = ctx->image0 != nullptr && !ctx->no_cost_order && !ctx->no_two_phase && spp >= 16;
+  for (int sl : {TDT_SLOT_CELLS, TDT_SLOT_MATERIALS, TDT_SLOT_ALBEDOS, TDT_SLOT_METAL, TDT_SLOT_DIELECTRIC, TDT_SLOT_OCTREE_FLOATS, TDT_SLOT_OCTREE_INTS})
+    ready = ready && ctx->ssbo[sl] != nullptr;
+  if (ready && ctx->ssbo[TDT_SLOT_OCTREE_FLOATS]->bytes >= 28 && ctx->ssbo[TDT_SLOT_OCTREE_INTS]->bytes >= 12) {
+    const Cover k = cover_of(c, width, height);
+    const Tiles t = tiles_of(c, k);
+    unsigned char sig[sizeof ctx->cost_sig];
+    make_sig(ctx, c, k, ctx->image0, sig);
+    const bool replay = ctx->cost_tiles == (uint32_t)t.owned && std::memcmp(sig, ctx->cost_sig, sizeof sig) == 0;
+    if (!replay && t.owned > 0) {
+      TDT_HIP(ctx, hipSetDevice(ctx->device));
+      const size_t px = (size_t)ctx->image0->w * (size_t)ctx->image0->h, slots = (size_t)t.owned * 1024;
+      const size_t need = (px > slots ? px : slots) * 16 * sizeof(float);
+      if (ctx->frame_carry_bytes < need) {
+        if (ctx->frame_carry) (void)hipFree(ctx->frame_carry);
+        ctx->frame_carry = nullptr; ctx->frame_carry_bytes = 0;
+        TDT_HIP(ctx, hipMalloc(&ctx->frame_carry, need));
+        ctx->frame_carry_bytes = need;
+      }
+      const int probe = spp / 16;
+      int rc = launch(c, width, height, depth, 1, 0, probe, ctx->frame_carry, 0, nullptr);
+      if (rc == TDT_OK) rc = launch(c, width, height, depth, 1, probe, spp - probe, ctx->frame_carry, 0, nullptr);
+      if (rc == TDT_OK) rc = launch(c, width, height, depth, 2, 0, 0, nullptr, spp, nullptr);
+      return rc;
+    }
+  }
+  return launch(c, width, height, depth, 0, 0, spp, nullptr, spp, nullptr);
 }
 
 int tdt_set_partition(tdt_compute *c, int rank, int world) {

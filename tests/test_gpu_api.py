@@ -209,6 +209,31 @@ def test_every_scheduling_variant_is_the_same_bits(oracle, monkeypatch, env):
         r.close()
 
 
+@pytest.mark.parametrize("cfg", [2, 3])
+def test_two_phase_frames_are_the_same_bits(oracle, monkeypatch, cfg):
+    """A frame without a usable cost history (first frame, moved camera) with spp >= 16 is traced as spp/16 probe samples,
+    then the rest in the cost order of its own probe, then a resolve — sums and hit-record carry through HBM in between.
+    It must equal the one-pass frame (TDT_NO_TWO_PHASE=1) and the oracle bit for bit."""
+    scene = host.Scene.config(cfg)
+    cam = host.camera_reference_pose(192, 128, 40, 6)                # probe = 2 samples
+    ref = oracle.render(scene, cam, threads=16)
+    r = rt.Renderer(scene, cam)
+    try:
+        assert _eq(r.render(), ref)                          # two-phase
+        assert _eq(r.render(), ref)                          # replay: one pass, exact order
+        cam2 = cam.copy(); cam2.origin[0] = 0.05; cam2.lower_left_corner[0] += 0.05
+        rt.initial_uniforms(cam2, r.shader.program)
+        assert _eq(r.render(), oracle.render(scene, cam2, threads=16))       # moved: two-phase again, stale tile order for the probe
+    finally:
+        r.close()
+    monkeypatch.setenv("TDT_NO_TWO_PHASE", "1")
+    r = rt.Renderer(scene, cam)
+    try:
+        assert _eq(r.render(), ref)
+    finally:
+        r.close()
+
+
 def test_cost_feedback_after_the_camera_moved(oracle):
     """When the inputs of a dispatch differ from what the recorded costs were measured on (camera moved, scene edited),
     8x8 tiles are ordered by their summed cost instead of single pixels; a repeat of the same view then goes back to
