@@ -1337,7 +1337,7 @@ int tdt_dispatch_compute(tdt_compute *c, int width, int height, int depth) {
         TDT_HIP(ctx, hipMalloc(&ctx->frame_carry, need));
         ctx->frame_carry_bytes = need;
       }
-      const int probe = spp / 16;
+      const int probe = spp / 16;                    // measured: 1/8 and 1/32 are 0-3 % slower, 1/64 5 %
       int rc = launch(c, width, height, depth, 1, 0, probe, ctx->frame_carry, 0, nullptr);
       if (rc == TDT_OK) rc = launch(c, width, height, depth, 1, probe, spp - probe, ctx->frame_carry, 0, nullptr);
       if (rc == TDT_OK) rc = launch(c, width, height, depth, 2, 0, 0, nullptr, spp, nullptr);
