@@ -134,53 +134,52 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   for (;;) {
     if (COUNT) pass_no++;
     // ------------------------------------------------------------ one traversal step rc:410-447
-    if (state == ST_TRAVERSE) {
-      if (COUNT) lane_S++;
-      if (COUNT) { cnt.trav_slots += slot64(); cnt.trav_active++; }
-      if (!(it < P.max_iter && t_stride < t_octree_max)) {
-        state = ST_END;                               // OctreeHit returns false rc:449
+    {
+      // Flat form: every lane evaluates the loop condition and the position (the values of lanes that are not traversing
+      // are never used), so the step is ONE exec region instead of three nested ones.
+      const bool trav = state == ST_TRAVERSE;
+      if (COUNT && trav) { lane_S++; cnt.trav_slots += slot64(); cnt.trav_active++; }
+      const bool go = trav && (it < P.max_iter) && (t_stride < t_octree_max);      // else: OctreeHit returns false rc:449
+      const float adv = f_max(0.0001f * (inv_pow_depth + 0.1f), 0.000001f);
+      const float tt = t_stride + adv;
+      const float wx = tt * r.dx + r.ox, wy = tt * r.dy + r.oy, wz = tt * r.dz + r.oz;
+      const float lx = (wx + -P.min_x) * P.inv_scale, ly = (wy + -P.min_y) * P.inv_scale, lz = (wz + -P.min_z) * P.inv_scale;
+      bool in_box;
+      if (POW2) {
+        // rc:417 "fract(p) - p != vec3(0)": fract(p) - p is zero exactly for p in [0,1) (and -0)
+        in_box = (lx >= 0.0f) & (lx < 1.0f) & (ly >= 0.0f) & (ly < 1.0f) & (lz >= 0.0f) & (lz < 1.0f);
       } else {
-        const float adv = f_max(0.0001f * (inv_pow_depth + 0.1f), 0.000001f);
-        const float tt = t_stride + adv;
-        const float wx = tt * r.dx + r.ox, wy = tt * r.dy + r.oy, wz = tt * r.dz + r.oz;
-        const float lx = (wx + -P.min_x) * P.inv_scale, ly = (wy + -P.min_y) * P.inv_scale, lz = (wz + -P.min_z) * P.inv_scale;
-        bool outside;
-        if (POW2) {
-          // rc:417 "fract(p) - p != vec3(0)": fract(p) - p is zero exactly for p in [0,1) (and -0)
-          outside = !((lx >= 0.0f) & (lx < 1.0f) & (ly >= 0.0f) & (ly < 1.0f) & (lz >= 0.0f) & (lz < 1.0f));
+        const float ex = f_fract(lx) + -lx, ey = f_fract(ly) + -ly, ez = f_fract(lz) + -lz;
+        in_box = !((__builtin_fabsf(ez) + __builtin_fabsf(ey)) != -__builtin_fabsf(ex));
+      }
+      const bool inside = go && in_box;
+      if (inside) {
+        float ugx, ugy, ugz; uint32_t value;
+        if (COUNT) cnt.iterations++;
+        const bool leaf = POW2 ? tree_lookup_pow2<COUNT, kMemoLevels, DEPTH, RESIDENT, SAFEV>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, memo, cnt)
+                               : tree_lookup<COUNT>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, cnt);
+        lane_work += kCostStep + (127u - (__float_as_uint(inv_pow_depth) >> 23));   // + tree levels visited (inv_pow_depth = 2^-levels)
+        const float bx = ugx * P.scale + P.min_x, by = ugy * P.scale + P.min_y, bz = ugz * P.scale + P.min_z;
+        const float cs0 = P.scale * inv_pow_depth;
+        // leaf: the exact cell (rc:427-428); empty: padded by -1e-5 / +2e-5 (rc:441-442)
+        const float cx = leaf ? bx : bx + -0.00001f, cy = leaf ? by : by + -0.00001f, cz = leaf ? bz : bz + -0.00001f;
+        const float cs = leaf ? cs0 : cs0 + 0.00002f;
+        float t_enter, t_exit;
+        cube_slabs(r, ix, iy, iz, cx, cy, cz, cs, t_stride, t_octree_max, t_enter, t_exit);
+        const bool cube_ok = !(t_exit < t_enter);
+        if (leaf) {
+          // CubeHit's record (rc:336-354) is deferred to the event code, where the lanes that hit
+          // are batched: only a few lanes per step reach a leaf.  The traversal registers are
+          // dead from here on, so they carry the cube.
+          leaf_box_x = cx; leaf_box_y = cy; leaf_box_z = cz; inv_pow_depth = cs; t_stride = t_enter;
+          use_leaf = it > 0; leaf_rec = it > 0 && cube_ok; hit_index = value;
+          state = ST_HIT;
         } else {
-          const float ex = f_fract(lx) + -lx, ey = f_fract(ly) + -ly, ez = f_fract(lz) + -lz;
-          outside = (__builtin_fabsf(ez) + __builtin_fabsf(ey)) != -__builtin_fabsf(ex);
-        }
-        if (outside) {
-          state = ST_END;
-        } else {
-          float ugx, ugy, ugz; uint32_t value;
-          if (COUNT) cnt.iterations++;
-          const bool leaf = POW2 ? tree_lookup_pow2<COUNT, kMemoLevels, DEPTH, RESIDENT, SAFEV>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, memo, cnt)
-                                 : tree_lookup<COUNT>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, cnt);
-          lane_work += kCostStep + (127u - (__float_as_uint(inv_pow_depth) >> 23));   // + tree levels visited (inv_pow_depth = 2^-levels)
-          const float bx = ugx * P.scale + P.min_x, by = ugy * P.scale + P.min_y, bz = ugz * P.scale + P.min_z;
-          const float cs0 = P.scale * inv_pow_depth;
-          // leaf: the exact cell (rc:427-428); empty: padded by -1e-5 / +2e-5 (rc:441-442)
-          const float cx = leaf ? bx : bx + -0.00001f, cy = leaf ? by : by + -0.00001f, cz = leaf ? bz : bz + -0.00001f;
-          const float cs = leaf ? cs0 : cs0 + 0.00002f;
-          float t_enter, t_exit;
-          cube_slabs(r, ix, iy, iz, cx, cy, cz, cs, t_stride, t_octree_max, t_enter, t_exit);
-          const bool cube_ok = !(t_exit < t_enter);
-          if (leaf) {
-            // CubeHit's record (rc:336-354) is deferred to the event code, where the lanes that hit
-            // are batched: only a few lanes per step reach a leaf.  The traversal registers are
-            // dead from here on, so they carry the cube.
-            leaf_box_x = cx; leaf_box_y = cy; leaf_box_z = cz; inv_pow_depth = cs; t_stride = t_enter;
-            use_leaf = it > 0; leaf_rec = it > 0 && cube_ok; hit_index = value;
-            state = ST_HIT;
-          } else {
-            t_stride = cube_ok ? t_exit : t_octree_max;
-            it++;
-          }
+          t_stride = cube_ok ? t_exit : t_octree_max;
+          it++;
         }
       }
+      state = (trav && !inside) ? ST_END : state;       // left the octree / ran out of iterations
     }
 
     TDT_TICK(0);
