@@ -214,7 +214,9 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       if (scatter<COUNT>(P, r, h, mat, nr, tr, tg, tb, cnt)) {
         ar = ar * tr; ag = ag * tg; ab = ab * tb;
         r = nr;
-        state = ST_NEWRAY;
+        // rc:271: the bounce limit ends the path here and now — ST_END is handled further down in this same pass; going
+        // through ST_NEWRAY first would make the lane wait for another event pass
+        state = loop_count < P.max_bounce ? ST_NEWRAY : ST_END;
       } else {
         state = ST_END;
       }
