@@ -70,7 +70,9 @@ enum : int { ST_TRAVERSE = 0, ST_HIT = 1, ST_END = 2, ST_FETCH = 3, ST_PRIMARY =
 // flag, looked at once per pixel, so the scene-specialised variants serve progressive passes too).
 // COUNT: instrumented build that also totals the events defining the algorithmic bytes.
 // POW2: exact-comparison treeLookup (see tree_lookup_pow2) vs the literal float form.
-template <bool COUNT, bool POW2, int DEPTH = 0, bool RESIDENT = false, bool SAFEV = false>
+// PROBE changes nothing but the kernel's name: the short probe launch of a two-phase frame (tdt_dispatch_compute) then shows
+// up as its own row in profiler statistics instead of halving the average of the launches that do the work.
+template <bool COUNT, bool POW2, int DEPTH = 0, bool RESIDENT = false, bool SAFEV = false, bool PROBE = false>
 __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   __shared__ __attribute__((aligned(16))) uint16_t s_nodes[kLdsCells * 8 + 8];   // + the sentinel slot
   for (uint32_t i = threadIdx.x * 8u; i < P.lds_nodes; i += (uint32_t)TDT_BLOCK * 8u)      // one cell (8 x u16) per lane and trip
@@ -704,6 +706,7 @@ struct tdt_ctx {
   float event_k;        // TDT_EVENT_K overrides the adaptive threshold's r (0: chosen from the tree size)
   void *frame_carry; size_t frame_carry_bytes;   // hit-record carry between the two phases of a frame (tdt_dispatch_compute)
   bool no_two_phase;                             // TDT_NO_TWO_PHASE=1
+  bool probe_launch;                             // set around the probe launch of a two-phase frame (kernel name only)
   uint32_t *present; size_t present_bytes;   // staging of tdt_image_read_rgba8
   uint32_t *pixel_log; size_t pixel_log_u32;   // TDT_PIXEL_LOG diagnostics (instrumented dispatches only)
   bool no_specialise;   // TDT_NO_SPECIALISE=1: never pick a scene-specialised kernel (A/B testing)
@@ -943,7 +946,9 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     bool launched = false;
     P.accumulate = mode == 1 ? 1 : 0;
     if (mode != 2 && !counts_out && pow2 && safev && !ctx->no_specialise) {
-#define TDT_SPEC(D, R) hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, R, true>), grid, block, 0, ctx->stream, P); launched = true; break
+#define TDT_SPEC(D, R) if (ctx->probe_launch) hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, R, true, true>), grid, block, 0, ctx->stream, P); \
+                       else hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, R, true>), grid, block, 0, ctx->stream, P); \
+                       launched = true; break
       if (resident) switch (P.max_depth) {
         case 3: TDT_SPEC(3, true); case 4: TDT_SPEC(4, true); case 5: TDT_SPEC(5, true); case 6: TDT_SPEC(6, true);
         case 7: TDT_SPEC(7, true); default: break; }
@@ -989,7 +994,7 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
   if (!ctx) return fail(nullptr, TDT_ERR_HIP, "out of host memory");
   ctx->device = device_id;
   for (auto &s : ctx->ssbo) s = nullptr;
-  ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr; ctx->queue = nullptr; ctx->packed = nullptr; ctx->packed_of = nullptr; ctx->packed_version = 0; ctx->present = nullptr; ctx->present_bytes = 0; ctx->frame_carry = nullptr; ctx->frame_carry_bytes = 0; ctx->pixel_log = nullptr; ctx->pixel_log_u32 = 0; ctx->slot_cost = ctx->slot_acc = ctx->slot_order = ctx->order_hist = nullptr; ctx->tile_capacity = ctx->cost_tiles = 0; ctx->cost_dispatches = 0;
+  ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr; ctx->queue = nullptr; ctx->packed = nullptr; ctx->packed_of = nullptr; ctx->packed_version = 0; ctx->present = nullptr; ctx->present_bytes = 0; ctx->frame_carry = nullptr; ctx->frame_carry_bytes = 0; ctx->probe_launch = false; ctx->pixel_log = nullptr; ctx->pixel_log_u32 = 0; ctx->slot_cost = ctx->slot_acc = ctx->slot_order = ctx->order_hist = nullptr; ctx->tile_capacity = ctx->cost_tiles = 0; ctx->cost_dispatches = 0;
   { const char *nc = getenv("TDT_NO_COST_ORDER"); ctx->no_cost_order = nc && nc[0] == '1';
     const char *fs = getenv("TDT_ORDER_SMOOTH"); ctx->force_smooth = fs ? atoi(fs) : -1;
     ctx->no_cost_accum = getenv("TDT_NO_COST_ACCUM") != nullptr;
@@ -1274,7 +1279,7 @@ int tdt_image_read_rgba8(tdt_image *img, int top_down, uint8_t *dst) {
   if (ctx->present_bytes < bytes) {
     if (ctx->present) (void)hipFree(ctx->present);
   if (ctx->frame_carry) (void)hipFree(ctx->frame_carry);
-    ctx->present = nullptr; ctx->present_bytes = 0; ctx->frame_carry = nullptr; ctx->frame_carry_bytes = 0;
+    ctx->present = nullptr; ctx->present_bytes = 0; ctx->frame_carry = nullptr; ctx->frame_carry_bytes = 0; ctx->probe_launch = false;
     TDT_HIP(ctx, hipMalloc((void **)&ctx->present, bytes));
     ctx->present_bytes = bytes;
   }
@@ -1334,12 +1339,14 @@ int tdt_dispatch_compute(tdt_compute *c, int width, int height, int depth) {
       const size_t need = (px > slots ? px : slots) * 16 * sizeof(float);
       if (ctx->frame_carry_bytes < need) {
         if (ctx->frame_carry) (void)hipFree(ctx->frame_carry);
-        ctx->frame_carry = nullptr; ctx->frame_carry_bytes = 0;
+        ctx->frame_carry = nullptr; ctx->frame_carry_bytes = 0; ctx->probe_launch = false;
         TDT_HIP(ctx, hipMalloc(&ctx->frame_carry, need));
         ctx->frame_carry_bytes = need;
       }
       const int probe = spp / 16;                    // measured: 1/8 and 1/32 are 0-3 % slower, 1/64 5 %
+      ctx->probe_launch = true;
       int rc = launch(c, width, height, depth, 1, 0, probe, ctx->frame_carry, 0, nullptr);
+      ctx->probe_launch = false;
       if (rc == TDT_OK) rc = launch(c, width, height, depth, 1, probe, spp - probe, ctx->frame_carry, 0, nullptr);
       if (rc == TDT_OK) rc = launch(c, width, height, depth, 2, 0, 0, nullptr, spp, nullptr);
       return rc;
