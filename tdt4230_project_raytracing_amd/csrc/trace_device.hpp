@@ -345,8 +345,10 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
   const float Yf = fy * scale_d, Zf = fz * scale_d;                        // exact
   const float Yfl = __builtin_floorf(Yf), Zfl = __builtin_floorf(Zf);
   uint32_t Yi = (uint32_t)Yfl, Zi = (uint32_t)Zfl;
-  Yi = (Yf == Yfl) ? (Yi & (Yi - 1u)) : Yi;
-  Zi = (Zf == Zfl) ? (Zi & (Zi - 1u)) : Zi;
+  if (__builtin_expect(__ballot((Yf == Yfl) | (Zf == Zfl)) != 0ull, 0)) {   // a coordinate exactly on a finest-level boundary: the tie rule
+    Yi = (Yf == Yfl) ? (Yi & (Yi - 1u)) : Yi;
+    Zi = (Zf == Zfl) ? (Zi & (Zi - 1u)) : Zi;
+  }
   uint32_t qx = 1u, v = 0, code = 1u;                 // qx: x digits below a sentinel bit that counts the levels visited
   const float fx0 = fx;
   bool jumped = false;
