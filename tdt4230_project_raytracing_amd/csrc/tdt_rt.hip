@@ -164,7 +164,9 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
         const float bx = ugx * P.scale + P.min_x, by = ugy * P.scale + P.min_y, bz = ugz * P.scale + P.min_z;
         const float cs0 = P.scale * inv_pow_depth;
         // leaf: the exact cell (rc:427-428); empty: padded by -1e-5 / +2e-5 (rc:441-442)
-        const float cx = leaf ? bx : bx + -0.00001f, cy = leaf ? by : by + -0.00001f, cz = leaf ? bz : bz + -0.00001f;
+        // (x + -0.0f is x, bit for bit, for every x: one select on the pad instead of one per coordinate)
+        const float pad = leaf ? -0.0f : -0.00001f;
+        const float cx = bx + pad, cy = by + pad, cz = bz + pad;
         const float cs = leaf ? cs0 : cs0 + 0.00002f;
         float t_enter, t_exit;
         cube_slabs(r, ix, iy, iz, cx, cy, cz, cs, t_stride, t_octree_max, t_enter, t_exit);

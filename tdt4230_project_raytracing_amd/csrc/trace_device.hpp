@@ -449,10 +449,14 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
   const int m = 31 - __builtin_clz(qx);               // levels visited
   qx ^= 1u << m;
   const float ipd = __uint_as_float((uint32_t)(127 - m) << 23);             // 2^-m = inv_pow_depth after m halvings
-  inv_pow_depth = (m == 0) ? 1.0f : ipd;
   const int sh = depth - m;
   gx = (float)qx * ipd; gy = (float)(Yi >> sh) * ipd; gz = (float)(Zi >> sh) * ipd;
-  if (m == 0) { gx = 0.f; gy = 0.f; gz = 0.f; }
+  if (DEPTH > 0) {
+    inv_pow_depth = ipd;                              // a compile-time depth >= 1: level 1 always runs, m >= 1
+  } else {
+    inv_pow_depth = (m == 0) ? 1.0f : ipd;            // max_depth 0: the loop body never ran
+    if (m == 0) { gx = 0.f; gy = 0.f; gz = 0.f; }
+  }
   value = v;
   return code == 2u;
 }
