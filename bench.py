@@ -49,6 +49,12 @@ def main():
                     help="run the N>1 code path (tile buffer, RCCL gather, de-interleave) even with one rank: a self-test")
     args = ap.parse_args()
 
+    # the contract is ONE JSON line on stdout: libraries that chat on fd 1 (RCCL prints a host / library banner when a
+    # communicator is created) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -256,7 +262,10 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     r.close()
     if sharded:
         dist.destroy_process_group()
