@@ -88,6 +88,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   NodeSource ns;
   ns.lds = s_nodes; ns.lds_nodes = P.lds_nodes; ns.lds_cells = (P.lds_nodes + 7u) >> 3;
   ns.grid = s_grid; ns.grid_ok = kUseGrid ? (__builtin_amdgcn_readfirstlane(s_grid_ok) != 0) : false;
+  ns.grid_band = ns.grid_ok ? kGridBand : 2.0f;
   ns.cells = __builtin_amdgcn_make_buffer_rsrc((void *)P.cells, 0, (int)((P.cells_dwords >> 1) << 3), 0x00020000);
   const uint32_t total_slots = (uint32_t)P.owned_tiles * 1024u;
 

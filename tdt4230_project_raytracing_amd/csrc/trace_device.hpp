@@ -156,7 +156,7 @@ struct NodeSource {
   uint32_t lds_nodes;                                 // valid entries
   uint32_t lds_cells;                                 // cells they make up (the last may be partial): index of the sentinel cell
   const uint32_t *grid;                               // top-level jump table (see build_top_grid), or unusable when !grid_ok
-  bool grid_ok;
+  bool grid_ok; float grid_band;                      // grid_band = kGridBand, or 2 when the table is unusable
   __amdgpu_buffer_rsrc_t cells;                       // raw buffer over the cells payload (8-byte granules)
 };
 
@@ -352,9 +352,9 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
   uint32_t qx = 1u, v = 0, code = 1u;                 // qx: x digits below a sentinel bit that counts the levels visited
   const float fx0 = fx;
   bool jumped = false;
-  if (!COUNT && DEPTH >= kGridLevels && ns.grid_ok) {   // the top levels in one step (see build_top_grid)
+  if (!COUNT && DEPTH >= kGridLevels) {              // the top levels in one step (see build_top_grid)
     const float tg = fx0 * (float)(1 << kGridLevels);  // exact
-    const bool safe = __builtin_fabsf(tg - __builtin_rintf(tg)) > kGridBand;
+    const bool safe = __builtin_fabsf(tg - __builtin_rintf(tg)) > ns.grid_band;   // (an unusable table has band 2: never safe)
     if (__builtin_expect(__ballot(!safe) == 0ull, 1)) {
       const uint32_t xg = (uint32_t)tg;               // floor: tg in [0, 2^kGridLevels)
       const uint32_t g = ns.grid[(xg << (2 * kGridLevels)) | ((Yi >> (depth - kGridLevels)) << kGridLevels) | (Zi >> (depth - kGridLevels))];
