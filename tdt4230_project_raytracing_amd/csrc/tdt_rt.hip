@@ -569,7 +569,7 @@ __global__ __launch_bounds__(1024) void order_hist_kernel(const uint32_t *__rest
   __syncthreads();
   if (threadIdx.x < 512 && s_bin[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_bin[threadIdx.x]);
 }
-__global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restrict__ cost, const uint32_t *__restrict__ acc, uint32_t n, const uint32_t *__restrict__ hist,
+__global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restrict__ cost, uint32_t *__restrict__ acc, uint32_t n, const uint32_t *__restrict__ hist,
                                                              uint32_t *__restrict__ cursor, uint32_t *__restrict__ order, uint32_t g, int smooth) {
   __shared__ uint32_t s_bin[512], s_base[512];
   if (threadIdx.x < 512) s_bin[threadIdx.x] = 0;
@@ -598,6 +598,9 @@ __global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restric
       order[atomicAdd(&s_base[order_key(acc[i], g)], 1u)] = i;
     }
     cost[i] = 0;
+    // tile-sum mode = the inputs changed: these costs served once, as a prior for this dispatch's order; the estimate for
+    // what follows (the second phase of this frame) starts over from what this dispatch measures
+    if (smooth) acc[i] = 0;
   }
 }
 
@@ -925,6 +928,7 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
         P.slot_order = ctx->slot_order;
       } else {                                        // no usable history: image order, fresh cost array
         TDT_HIP(ctx, hipMemsetAsync(ctx->slot_cost, 0, (size_t)t.owned * 1024 * sizeof(uint32_t), ctx->stream));
+        TDT_HIP(ctx, hipMemsetAsync(ctx->slot_acc, 0, (size_t)t.owned * 1024 * sizeof(uint32_t), ctx->stream));
         ctx->cost_dispatches = 0;
       }
       std::memcpy(ctx->cost_sig, sig, sizeof sig);
