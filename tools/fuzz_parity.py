@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Randomised parity sweep: generated scenes x cameras (inside / outside the octree, axis-aligned views that put rays exactly on
 cell boundaries, odd image sizes, spp above and below the two-phase limit), GPU frames (first = two-phase or image order, then a
-cost-ordered replay) against the oracle, bit for bit.  usage: fuzz_parity.py [seconds] [seed]"""
+cost-ordered replay; a random progressive split; a 2-4 rank work-group partition) against the oracle, bit for bit.  usage: fuzz_parity.py [seconds] [seed]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 import numpy as np
+import torch
 from tdt4230_project_raytracing_amd import host, rt
 import oracle_py
 
@@ -45,6 +46,35 @@ while time.time() - t0 < budget:
                       f"{int((got.view(np.uint32) != ref.view(np.uint32)).any(axis=2).sum())} px", flush=True)
     finally:
         r.close()
+    how = int(rng.integers(0, 4))
+    if how == 1 and spp >= 2:                                      # progressive: running sums + carry over a random split, then resolve
+        a = int(rng.integers(1, spp))
+        acc = torch.zeros((cam.image_height, W, 4), dtype=torch.float32, device="cuda:0")
+        carry = torch.zeros((cam.image_height, W, 16), dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        r = rt.Renderer(scene, cam, image_ptr=acc.data_ptr())
+        try:
+            r.shader.dispatch_accumulate(W + 1, cam.image_height + 1, 1, 0, a, carry.data_ptr())
+            r.shader.dispatch_accumulate(W + 1, cam.image_height + 1, 1, a, spp - a, carry.data_ptr())
+            r.shader.dispatch_resolve(W + 1, cam.image_height + 1, 1, spp)
+            got = r.texture.read()
+        finally:
+            r.close()
+        if not (got.view(np.uint32) == ref.view(np.uint32)).all():
+            bad += 1; print(f"MISMATCH progressive split {a}/{spp} kind {kind} depth {depth} {W}x{H}", flush=True)
+    elif how == 2:                                                 # work-group partition over 2-4 ranks into one image
+        world = int(rng.integers(2, 5))
+        full = torch.zeros((cam.image_height, W, 4), dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        for rank in range(world):
+            r = rt.Renderer(scene, cam, rank=rank, world=world, image_ptr=full.data_ptr())
+            try:
+                r.dispatch(); r.ctx.finish()
+            finally:
+                r.close()
+        got = full.cpu().numpy()
+        if not (got.view(np.uint32) == ref.view(np.uint32)).all():
+            bad += 1; print(f"MISMATCH partition world {world} kind {kind} depth {depth} {W}x{H}", flush=True)
     n += 1
     if n % 20 == 0:
         print(f"{n} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
