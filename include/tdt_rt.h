@@ -70,6 +70,21 @@ enum {
 /* Replaces GL context creation + make_current (main.rs:58-61,108-112).  `stream` is a
  * hipStream_t to launch on (NULL: the context creates its own non-blocking stream). */
 int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out);
+/* ONE context over n_devices GPUs, driven by the one thread that owns it — the reference's shape (a single
+ * GL context on a single thread, main.rs:58-61,105-112), so a host bound per INTEGRATION.md drives a whole node without
+ * knowing it.  Every call on the returned context and on handles created from it means what it means on a single-device
+ * context: buffer uploads / sub-data / binds / uniforms / edit dispatches are replicated to every device (the scene is
+ * read-only and small: <= 64 MB against 288 GB); tdt_dispatch_compute of the raytracer launches each device's share of the
+ * 32x32 work-groups (t % n == i, as tdt_set_partition) on that device's own stream, brings the per-device tile buffers to
+ * the first device with ONE RCCL gather (librccl.so.1, loaded on first use; a single-process communicator over the
+ * devices) and de-interleaves them there into the bound image, so tdt_image_read / tdt_image_read_rgba8 /
+ * tdt_image_device_ptr see the assembled frame on device_ids[0].  Device ids may repeat (several shares on one GPU — how
+ * the path is tested on a one-GPU box); RCCL cannot form a communicator then and the gather becomes peer copies ordered
+ * by events (TDT_MULTI_TRANSPORT=copy forces that, =rccl forbids it).  Not available on a multi-device context (they
+ * return TDT_ERR_INVALID_OPERATION): tdt_set_partition, tdt_dispatch_accumulate / _resolve / _counted_range. */
+int tdt_ctx_create_multi(int n_devices, const int *device_ids, tdt_ctx **out);
+/* number of devices behind a context (1 for tdt_ctx_create) */
+int tdt_ctx_device_count(const tdt_ctx *ctx);
 void tdt_ctx_destroy(tdt_ctx *ctx);
 /* glFinish: block until every dispatch of this context has completed. */
 int tdt_finish(tdt_ctx *ctx);
@@ -166,6 +181,57 @@ int tdt_dispatch_resolve(tdt_compute *c, int width, int height, int depth, int t
  * [3] Node loads (tree levels visited), [4] Lambertian, [5] metal, [6] dielectric scatters,
  * [7] hits on unknown material types.  Synchronous.  These define the algorithmic bytes. */
 int tdt_dispatch_counted(tdt_compute *c, int width, int height, int depth, uint64_t counts[8]);
+/* the same for one launch of a progressive frame: tdt_dispatch_accumulate(.., spp_begin, spp_count, carry), instrumented */
+int tdt_dispatch_counted_range(tdt_compute *c, int width, int height, int depth, int spp_begin, int spp_count,
+                               void *carry_device_ptr, uint64_t counts[8]);
+/* Drop the per-pixel cost history of the context: the next tdt_dispatch_compute is scheduled like the first frame of a
+ * context (two-phase, probe in image order) whatever was traced before.  Only the schedule changes, never a pixel.
+ * (Measurement: bench.py times frames "the scheduler has not seen" with it.) */
+int tdt_forget_costs(tdt_ctx *ctx);
+/* measurement aid: enable != 0 records HIP events around the launches of every following tdt_dispatch_compute; ms (may be
+ * NULL) receives the times of the LAST frame: {probe launch, main launch (+ the sort that orders it), resolve} for a
+ * two-phase frame, {0, the one launch, 0} otherwise.  Blocks until that frame has finished. */
+int tdt_debug_phase_timing(tdt_ctx *ctx, int enable, float ms[3]);
+/* multi-device contexts: times of the last raytracer dispatch — trace_ms[i] for each device (its own events), then on the
+ * first device gather_ms (from the end of ITS trace to the end of the gather: includes waiting for the slowest device) and
+ * assemble_ms.  Blocks until the frame has finished. */
+int tdt_debug_multi_timing(tdt_ctx *ctx, float *trace_ms /* n_devices */, float *gather_ms, float *assemble_ms);
+/* which transport the last gather of a multi-device context used: "rccl", "copy", or "" */
+const char *tdt_debug_multi_transport(const tdt_ctx *ctx);
+
+/* ---- scene ingest on the GPU ------------------------------------------------------------------------
+ * The step the reference never wrote (its call is commented out, main.rs:218-224): turn the voxel list its PLY loader
+ * yields (ply_point_loader.rs:102-319: PlyFileContent{voxels, albedos, min_point}) into the indirect-cell octree
+ * raytracer.comp reads.  Everything between the upload of the voxel list and the finished buffers runs in HIP kernels:
+ * Morton keys (x, y, z bit of a level = one child digit, most significant level first) -> stable LSD radix sort ->
+ * last-duplicate-wins unique -> per level, bottom-up, segment heads + prefix sum + 8-child reduce (uniform subtrees merge
+ * into one LEAF) -> one prefix sum over the MIXED flags of all levels = breadth-first cell numbers -> node emission.
+ * Byte-identical to the host builder (tdt_scene_from_ply / tdt_scene_generate in libtdthost.so). */
+/* core: n voxels {x, y, z, material index + 1 (1..254)} in grid coordinates [0, 2^depth)^3 (others are dropped; of
+ * duplicates the last wins) -> a new cells buffer of *n_cells cells (64 B each) on the context. */
+int tdt_octree_build_cells(tdt_ctx *ctx, const int32_t *voxels_xyzm, size_t n_voxels, int depth, tdt_buffer **cells,
+                           uint32_t *n_cells);
+/* the whole of tdt_scene_from_ply on the GPU: voxels {x, y, z, colour key}, the loader's min_point and palette
+ * (key -> r,g,b; n_palette entries in ascending key order).  Creates the seven buffers raytracer.comp reads and returns
+ * them in out_slots[0,1,2,3,4,6,7] (out_slots[5] = NULL) WITHOUT binding them; *max_depth / *cell_count are what
+ * OctreeInts holds (cell_count = the smallest power of two >= 1024 that holds the tree). */
+int tdt_octree_build_from_points(tdt_ctx *ctx, const int32_t *voxels_xyzk, size_t n_voxels, const int32_t min_point[3],
+                                 const uint32_t *palette_keys, const uint8_t *palette_rgb, size_t n_palette, int z_up,
+                                 int max_iter, tdt_buffer *out_slots[8], int32_t *max_depth, int32_t *cell_count);
+
+/* ---- voxel edits --------------------------------------------------------------------------------------
+ * tdt_dispatch_compute of a TDT_PROGRAM_OCTREE_UPDATE program runs octree_update.comp's invocations.  The reference's
+ * invocations race when their paths collide (its own comment, octree_update.comp:70-71); the defined result here is the
+ * one its only runnable implementation produces — invocations one after the other, x fastest.  A dispatch of more than one
+ * invocation is executed in parallel when that provably gives the same bytes: a planning pass walks every invocation's path
+ * read-only, marks the nodes it would write, allocates the cells it needs by a prefix sum over the invocations (so each gets
+ * the counter values the serial order would hand it), and checks that no invocation reads or writes a node another one
+ * writes and that the cells to be allocated are untouched; then one lane per invocation applies its edit.  Any doubt
+ * (collision, a walk that leaves the buffer, a non-empty node in the free pool) and the ordered one-lane walk runs instead
+ * — decided on the device, no host round trip.  mode: 0 = as described, 1 = always the ordered walk. */
+int tdt_debug_edit_mode(tdt_ctx *ctx, int mode);
+/* which path the last edit dispatch of the context took: 0 none yet, 1 ordered walk, 2 parallel.  Synchronises. */
+int tdt_debug_last_edit_path(tdt_ctx *ctx);
 /* lane-utilisation diagnostics of the last tdt_dispatch_counted of this context (32 totals; layout in
  * csrc/trace_device.hpp `Counters`); development aid */
 int tdt_debug_counters(tdt_ctx *ctx, uint64_t out[32]);

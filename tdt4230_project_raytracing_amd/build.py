@@ -43,12 +43,33 @@ def build_host(force=False):
     return out
 
 
-def build_device(force=False, extra_flags=()):
-    out = os.path.join(_HERE, "libtdtrt.so")
-    srcs = [os.path.join(CSRC, f) for f in ("tdt_rt.hip", "trace_device.hpp", "trace_params.h")] + \
-           [os.path.join(INCLUDE, "tdt_rt.h"), os.path.abspath(__file__)]
-    if force or _newer(out, srcs):
-        _run([HIPCC] + HIP_FLAGS + list(extra_flags) + ["-I", INCLUDE, "-I", CSRC, srcs[0], "-o", out])
+DEVICE_UNITS = ("tdt_rt.hip", "tdt_multi.hip", "tdt_build.hip", "tdt_edit.hip")
+DEVICE_HEADERS = ("trace_device.hpp", "trace_params.h", "tdt_internal.hpp", "device_scan.hpp")
+
+
+def build_device(force=False, extra_flags=(), out=None):
+    """libtdtrt.so: one object per translation unit (compiled side by side: the trace kernels take ~15 s, the rest
+    seconds), then one link.  Objects live in csrc/obj/ (git- and gpurun-ignored); only the .so travels."""
+    out = out or os.path.join(_HERE, "libtdtrt.so")
+    hdrs = [os.path.join(CSRC, f) for f in DEVICE_HEADERS] + [os.path.join(INCLUDE, "tdt_rt.h"), os.path.abspath(__file__)]
+    srcs = [os.path.join(CSRC, f) for f in DEVICE_UNITS]
+    if not (force or extra_flags or _newer(out, srcs + hdrs)):
+        return out
+    objdir = os.path.join(CSRC, "obj" + ("_" + str(abs(hash(tuple(extra_flags))) % 100000) if extra_flags else ""))
+    os.makedirs(objdir, exist_ok=True)
+    compile_flags = [f for f in HIP_FLAGS if f != "-shared"] + list(extra_flags)
+    jobs = []
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if force or extra_flags or _newer(obj, [src] + hdrs):
+            jobs.append((subprocess.Popen([HIPCC] + compile_flags + ["-I", INCLUDE, "-I", CSRC, "-c", src, "-o", obj],
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True), src))
+    for p, src in jobs:
+        log, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("build failed: " + src + "\n" + log)
+    objs = [os.path.join(objdir, os.path.basename(src) + ".o") for src in srcs]
+    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out, "-ldl"])
     return out
 
 

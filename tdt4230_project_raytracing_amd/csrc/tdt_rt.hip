@@ -480,48 +480,6 @@ __global__ __launch_bounds__(256) void selftest_kernel(int which, unsigned long 
   if ((threadIdx.x & 63) == 0 && bad) atomicAdd(mismatches, bad);
 }
 
-// ---- next row §8f-2: assets/shaders/octree_update.comp (uc:N = its line N) ------------------------
-// One voxel edit per invocation: walk max_depth-1 levels with treeLookup's index arithmetic, turning
-// EMPTY nodes on the way into PARENTs of freshly counted cells (atomicCompSwap + atomic counter,
-// uc:72-74), then overwrite the last node visited with the delta (uc:101).  The reference's
-// invocations race when their paths collide (its own comment, uc:70-71); the only implementation of
-// it that can be run (llvmpipe) executes work-groups one after the other, and that order is what
-// this kernel reproduces: ONE lane walks the dispatch in x-fastest order, so results are
-// deterministic and equal to the oracle's.  Edits are a handful of nodes; speed is irrelevant.
-__global__ __launch_bounds__(64) void octree_update_kernel(uint32_t *cells, uint32_t cells_dwords, const uint32_t *delta,
-                                                          uint32_t delta_dwords, float inv_cell_count, int max_depth,
-                                                          int cell_count, uint32_t *counter, int gx, int gy, int gz) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const float two_cc = (float)(int32_t)((uint32_t)cell_count << 1);
-  for (int z = 0; z < gz; z++) for (int y = 0; y < gy; y++) for (int x = 0; x < gx; x++) {
-    const uint32_t dof = ((uint32_t)x + (uint32_t)y + (uint32_t)z) << 5;      // delta_index uc:99, DeltaNode stride 32
-    float cx = __uint_as_float(ld_dw(delta, delta_dwords, dof)), cy = __uint_as_float(ld_dw(delta, delta_dwords, dof + 4)),
-          cz = __uint_as_float(ld_dw(delta, delta_dwords, dof + 8));
-    const float d_type = __uint_as_float(ld_dw(delta, delta_dwords, dof + 12)), d_value = __uint_as_float(ld_dw(delta, delta_dwords, dof + 16));
-    uint32_t node_value = 0, index = 0;
-    for (float i = 0.0f; i < (float)(max_depth - 1); i = i + 1.0f) {          // treeLookupLeaf uc:57-80
-      const float fx = f_fract(cx), fy = f_fract(cy), fz = f_fract(cz);
-      const float rx = __builtin_rintf((((float)node_value + fx) * inv_cell_count) * two_cc + -0.5f);
-      const float ry = __builtin_rintf(fy * 2.0f + -0.5f), rz = __builtin_rintf(fz * 2.0f + -0.5f);
-      index = ((((uint32_t)f2i(rx) << 1) + (uint32_t)f2i(ry)) << 1) + (uint32_t)f2i(rz);
-      const uint32_t dw = (index << 3) >> 2;
-      const uint32_t old = (dw + 1u < cells_dwords) ? cells[dw + 1u] : 0u;      // an out-of-range atomic returns 0, writes nothing
-      if (old == 0u) {
-        const uint32_t fresh = (*counter)++;
-        if (dw + 1u < cells_dwords) cells[dw + 1u] = 1u;
-        if (dw < cells_dwords) cells[dw] = fresh;
-      }
-      node_value = (dw < cells_dwords) ? cells[dw] : 0u;                        // node = indirect_cells[index] uc:76
-      cx = cx * 2.0f; cy = cy * 2.0f; cz = cz * 2.0f;
-    }
-    const uint32_t dw = (index << 3) >> 2;
-    const uint32_t uv = !(d_value > -1.0f) ? 0u : (d_value >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)d_value);
-    const uint32_t ut = !(d_type > -1.0f) ? 0u : (d_type >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)d_type);
-    if (dw < cells_dwords) cells[dw] = uv;                                      // uc:101
-    if (dw + 1u < cells_dwords) cells[dw + 1u] = ut;
-  }
-}
-
 // Cost-feedback scheduling.  A lane owns a pixel for all of its samples (they are sequential) and a frame is
 // only ~8 pixels per lane, so in image order a frame ends with a long tail (the queue runs dry after 60-85 %
 // of the kernel) and its waves mix sky pixels with deep ones.  The trace kernel therefore records the work of
@@ -665,73 +623,13 @@ __global__ __launch_bounds__(256) void assemble_kernel(const float4 *__restrict_
 }  // namespace tdt
 
 // ============================================================================ host ABI =====
+#include "tdt_internal.hpp"
+
 namespace {
 thread_local std::string g_create_err;
-constexpr int kNumSlots = 8;
 }
 
-struct tdt_buffer {
-  tdt_ctx *ctx;
-  void *dev;
-  size_t bytes;
-  unsigned long long version;   // bumped by every write: invalidates derived data (LDS table image)
-  unsigned char shadow[64];   // first bytes, host side: the octree uniform blocks are read from here
-};
-
-struct tdt_image {
-  tdt_ctx *ctx;
-  float *dev;
-  int w, h;
-  bool owned;
-};
-
-struct tdt_ctx {
-  int device;
-  hipStream_t stream;
-  bool own_stream;
-  std::string err;
-  tdt_buffer *ssbo[kNumSlots];
-  tdt_buffer *atomic0;
-  tdt_image *image0;
-  unsigned long long *counters;
-  unsigned int *queue;          // pixel-queue head
-  uint16_t *packed;             // LDS-table image of the bound cells buffer
-  const tdt_buffer *packed_of;  // which buffer/version `packed` was built from
-  unsigned long long packed_version;
-  uint32_t *slot_cost, *slot_acc, *slot_order, *order_hist;   // per queue slot: cost feedback of the last trace dispatch, the hand-out order derived from it; 2 x 256 sort counters
-  uint32_t cost_dispatches;            // dispatches summed into slot_cost so far
-  uint32_t tile_capacity, cost_tiles;  // allocation size (work-groups); number of work-groups slot_cost holds the last dispatch's costs for (0: none)
-  unsigned char cost_sig[256];         // what those costs were measured on (camera, octree parameters, buffer versions, partition)
-  bool no_cost_order;           // TDT_NO_COST_ORDER=1: always hand work-groups out in image order
-  uint32_t *scan;               // device scratch of scan_cells_kernel
-  uint32_t max_parent_value, max_any_value;   // its result for `packed_of`
-  int num_cus;
-  bool force_generic;   // TDT_FORCE_GENERIC=1: always run the literal-arithmetic kernel (A/B testing)
-  int event_threshold;  // TDT_EVENT_THRESHOLD=n fixes the event threshold (experiments); 0 = adaptive
-  int force_smooth; bool no_cost_accum; float max_share;   // TDT_ORDER_SMOOTH / TDT_NO_COST_ACCUM / TDT_MAX_SHARE (diagnostics)
-  float event_k;        // TDT_EVENT_K overrides the adaptive threshold's r (0: chosen from the tree size)
-  void *frame_carry; size_t frame_carry_bytes;   // hit-record carry between the two phases of a frame (tdt_dispatch_compute)
-  bool no_two_phase;                             // TDT_NO_TWO_PHASE=1
-  bool probe_launch;                             // set around the probe launch of a two-phase frame (kernel name only)
-  uint32_t *present; size_t present_bytes;   // staging of tdt_image_read_rgba8
-  uint32_t *pixel_log; size_t pixel_log_u32;   // TDT_PIXEL_LOG diagnostics (instrumented dispatches only)
-  bool no_specialise;   // TDT_NO_SPECIALISE=1: never pick a scene-specialised kernel (A/B testing)
-  std::vector<tdt_buffer *> buffers;
-  std::vector<tdt_image *> images;
-  std::vector<tdt_compute *> computes;
-};
-
-struct tdt_compute {
-  tdt_ctx *ctx;
-  int kind;
-  // `uniform Camera camera` raytracer.comp:133-146; GL initialises uniforms to 0
-  int32_t image_width, image_height, samples_per_pixel, max_bounce;
-  float horizontal[3], vertical[3], lower_left_corner[3], origin[3];
-  int part_rank, part_world;
-};
-
-namespace {
-
+namespace tdt {
 int fail(tdt_ctx *ctx, int code, const std::string &msg) {
   if (ctx) ctx->err = msg; else g_create_err = msg;
   return code;
@@ -739,15 +637,11 @@ int fail(tdt_ctx *ctx, int code, const std::string &msg) {
 int hip_fail(tdt_ctx *ctx, hipError_t e, const char *what) {
   return fail(ctx, TDT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
-#define TDT_HIP(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail((ctx), e_, #call); } while (0)
-
-template <class T> void erase_from(std::vector<T *> &v, T *p) {
-  for (size_t i = 0; i < v.size(); i++) if (v[i] == p) { v.erase(v.begin() + i); return; }
-}
+}  // namespace tdt
+using tdt::fail; using tdt::hip_fail; using tdt::erase_from; using tdt::Cover; using tdt::Tiles; using tdt::cover_of; using tdt::tiles_of;
 
 // ComputeShader::dispatch_compute's group arithmetic (compute_shader.rs:30-32) and what it covers
-struct Cover { int groups_x, groups_y, cover_w, cover_h; };
-Cover cover_of(const tdt_compute *c, int width, int height) {
+Cover tdt::cover_of(const tdt_compute *c, int width, int height) {
   Cover k;
   k.groups_x = width / 32 < 1 ? 1 : width / 32;
   k.groups_y = height / 32 < 1 ? 1 : height / 32;
@@ -759,14 +653,14 @@ Cover cover_of(const tdt_compute *c, int width, int height) {
   return k;
 }
 // 32x32 work-groups of the covered image and the ones this rank owns (t % world == rank)
-struct Tiles { int tiles_x, tiles_y, total, owned; };
-Tiles tiles_of(const tdt_compute *c, const Cover &k) {
+Tiles tdt::tiles_of(const tdt_compute *c, const Cover &k) {
   Tiles t;
   t.tiles_x = (k.cover_w + 31) / 32; t.tiles_y = (k.cover_h + 31) / 32;
   t.total = t.tiles_x * t.tiles_y;
   t.owned = t.total > c->part_rank ? (t.total - c->part_rank + c->part_world - 1) / c->part_world : 0;
   return t;
 }
+namespace {
 int64_t owned_pixels(const tdt_compute *c, const Cover &k) {
   Tiles t = tiles_of(c, k);
   int64_t n = 0;
@@ -779,18 +673,17 @@ int64_t owned_pixels(const tdt_compute *c, const Cover &k) {
   return n;
 }
 
-// What a trace dispatch depends on besides the sample range: camera, octree parameters, buffer identities and versions,
-// partition, covered size — compared with what the recorded pixel costs were measured on (see launch()).
-void make_sig(const tdt_ctx *ctx, const tdt_compute *c, const Cover &k, const tdt_image *img, unsigned char *sig) {
-  float of[7]; int32_t oi[3];
-  std::memcpy(of, ctx->ssbo[TDT_SLOT_OCTREE_FLOATS]->shadow, sizeof of);
-  std::memcpy(oi, ctx->ssbo[TDT_SLOT_OCTREE_INTS]->shadow, sizeof oi);
-  std::memset(sig, 0, sizeof ctx->cost_sig);
-  size_t o = 0;
-  auto put = [&](const void *p, size_t n) { if (o + n <= sizeof ctx->cost_sig) { std::memcpy(sig + o, p, n); o += n; } };
-  put(&c->image_width, sizeof(int32_t) * 4); put(c->horizontal, sizeof(float) * 12); put(&c->part_rank, sizeof(int) * 2);
-  put(of, sizeof of); put(oi, sizeof oi); put(&k.cover_w, sizeof k.cover_w); put(&k.cover_h, sizeof k.cover_h); put(&img->w, sizeof img->w); put(&img->h, sizeof img->h);
-  for (int sl = 0; sl < kNumSlots; sl++) if (ctx->ssbo[sl]) { put(&ctx->ssbo[sl], sizeof(void *)); put(&ctx->ssbo[sl]->version, sizeof ctx->ssbo[sl]->version); }
+// camera, octree parameters, buffer identities and versions, partition, covered size of the dispatch about to be traced
+void make_sig(const tdt_ctx *ctx, const tdt_compute *c, const Cover &k, const tdt_image *img, CostSig *sig) {
+  std::memset(sig, 0, sizeof *sig);                   // padding too: signatures are compared with memcmp
+  std::memcpy(sig->cam_i, &c->image_width, sizeof sig->cam_i);
+  std::memcpy(sig->cam_f, c->horizontal, sizeof sig->cam_f);
+  sig->part[0] = c->part_rank; sig->part[1] = c->part_world;
+  std::memcpy(sig->octree_f, ctx->ssbo[TDT_SLOT_OCTREE_FLOATS]->shadow, sizeof sig->octree_f);
+  std::memcpy(sig->octree_i, ctx->ssbo[TDT_SLOT_OCTREE_INTS]->shadow, sizeof sig->octree_i);
+  sig->cover[0] = k.cover_w; sig->cover[1] = k.cover_h; sig->image[0] = img->w; sig->image[1] = img->h;
+  for (int sl = 0; sl < kNumSlots; sl++)
+    if (ctx->ssbo[sl]) { sig->slot[sl].buffer = ctx->ssbo[sl]; sig->slot[sl].version = ctx->ssbo[sl]->version; }
 }
 
 int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_begin, int spp_count, void *carry,
@@ -902,11 +795,11 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
       // (the camera moved, the scene was edited) only the low-frequency part of the cost image is still true, and 8x8
       // tiles are sorted by their summed cost — measured on a 60 fps walk, exact-order-of-a-stale-frame is no better
       // than image order (256^3: 3 % worse), the tile form keeps about half of the gain
-      unsigned char sig[sizeof ctx->cost_sig];
-      make_sig(ctx, c, k, img, sig);
+      CostSig sig;
+      make_sig(ctx, c, k, img, &sig);
       P.slot_cost = ctx->slot_cost;
       if (ctx->cost_tiles == (uint32_t)t.owned) {
-        const int smooth = ctx->force_smooth >= 0 ? ctx->force_smooth : (std::memcmp(sig, ctx->cost_sig, sizeof sig) != 0 ? 1 : 0);
+        const int smooth = ctx->force_smooth >= 0 ? ctx->force_smooth : (std::memcmp(&sig, &ctx->cost_sig, sizeof sig) != 0 ? 1 : 0);
         // same inputs again (progressive passes, repeated frames): keep adding to the costs — every pass sharpens the
         // estimate of what a pixel costs; otherwise start over
         const bool keep_costs = !smooth && !ctx->no_cost_accum && ctx->cost_dispatches < 256;   // (restart before the sums can saturate)
@@ -931,7 +824,7 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
         TDT_HIP(ctx, hipMemsetAsync(ctx->slot_acc, 0, (size_t)t.owned * 1024 * sizeof(uint32_t), ctx->stream));
         ctx->cost_dispatches = 0;
       }
-      std::memcpy(ctx->cost_sig, sig, sizeof sig);
+      ctx->cost_sig = sig;
       ctx->cost_tiles = (uint32_t)t.owned;            // the kernel launched below records this dispatch's costs
     }
     TDT_HIP(ctx, hipMemsetAsync(ctx->queue, 0, sizeof(unsigned int), ctx->stream));
@@ -985,6 +878,25 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
 
 }  // namespace
 
+static unsigned long long next_buffer_version() {
+  static std::atomic<unsigned long long> next_version{1};   // contexts may live on different threads
+  return next_version.fetch_add(1);
+}
+
+int tdt::adopt_device_buffer(tdt_ctx *ctx, void *dev, size_t bytes, tdt_buffer **out) {
+  tdt_buffer *b = new (std::nothrow) tdt_buffer();
+  if (!b) return fail(ctx, TDT_ERR_HIP, "out of host memory");
+  b->ctx = ctx; b->bytes = bytes; b->dev = dev; b->version = next_buffer_version();
+  const size_t head = bytes < sizeof b->shadow ? bytes : sizeof b->shadow;
+  hipError_t e = hipSetDevice(ctx->device);
+  if (e == hipSuccess && head) e = hipMemcpyAsync(b->shadow, dev, head, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) { delete b; return hip_fail(ctx, e, "adopt_device_buffer"); }
+  ctx->buffers.push_back(b);
+  *out = b;
+  return TDT_OK;
+}
+
 extern "C" {
 
 int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
@@ -1001,7 +913,7 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
   if (!ctx) return fail(nullptr, TDT_ERR_HIP, "out of host memory");
   ctx->device = device_id;
   for (auto &s : ctx->ssbo) s = nullptr;
-  ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr; ctx->queue = nullptr; ctx->packed = nullptr; ctx->packed_of = nullptr; ctx->packed_version = 0; ctx->present = nullptr; ctx->present_bytes = 0; ctx->frame_carry = nullptr; ctx->frame_carry_bytes = 0; ctx->probe_launch = false; ctx->pixel_log = nullptr; ctx->pixel_log_u32 = 0; ctx->slot_cost = ctx->slot_acc = ctx->slot_order = ctx->order_hist = nullptr; ctx->tile_capacity = ctx->cost_tiles = 0; ctx->cost_dispatches = 0;
+  ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr; ctx->queue = nullptr; ctx->packed = nullptr; ctx->packed_of = nullptr; ctx->packed_version = 0; ctx->present = nullptr; ctx->present_bytes = 0; ctx->frame_carry = nullptr; ctx->frame_carry_bytes = 0; ctx->probe_launch = false; ctx->phase_timing = false; ctx->phase_n = 0; ctx->pixel_log = nullptr; ctx->pixel_log_u32 = 0; ctx->slot_cost = ctx->slot_acc = ctx->slot_order = ctx->order_hist = nullptr; ctx->tile_capacity = ctx->cost_tiles = 0; ctx->cost_dispatches = 0;
   { const char *nc = getenv("TDT_NO_COST_ORDER"); ctx->no_cost_order = nc && nc[0] == '1';
     const char *fs = getenv("TDT_ORDER_SMOOTH"); ctx->force_smooth = fs ? atoi(fs) : -1;
     ctx->no_cost_accum = getenv("TDT_NO_COST_ACCUM") != nullptr;
@@ -1025,6 +937,7 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
 
 void tdt_ctx_destroy(tdt_ctx *ctx) {
   if (!ctx) return;
+  if (ctx->multi) { tdt::multi_destroy(ctx); return; }
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (tdt_compute *c : ctx->computes) delete c;
@@ -1041,12 +954,15 @@ void tdt_ctx_destroy(tdt_ctx *ctx) {
   if (ctx->pixel_log) (void)hipFree(ctx->pixel_log);
   if (ctx->present) (void)hipFree(ctx->present);
   if (ctx->frame_carry) (void)hipFree(ctx->frame_carry);
+  if (ctx->phase_timing) for (auto &e : ctx->phase_ev) (void)hipEventDestroy(e);
+  tdt::edit_scratch_destroy(ctx);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
 
 int tdt_finish(tdt_ctx *ctx) {
   if (!ctx) return TDT_ERR_INVALID_VALUE;
+  if (ctx->multi) return tdt::multi_finish(ctx);
   TDT_HIP(ctx, hipSetDevice(ctx->device));
   TDT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return TDT_OK;
@@ -1073,10 +989,10 @@ int tdt_compute_create(tdt_ctx *ctx, int kind, tdt_compute **out) {
   *out = nullptr;
   if (kind != TDT_PROGRAM_RAYTRACER && kind != TDT_PROGRAM_OCTREE_UPDATE)
     return fail(ctx, TDT_ERR_INVALID_ENUM, "unknown program kind");
+  if (ctx->multi) return tdt::multi_compute_create(ctx, kind, out);
   tdt_compute *c = new (std::nothrow) tdt_compute();
   if (!c) return fail(ctx, TDT_ERR_HIP, "out of host memory");
-  std::memset(c, 0, sizeof *c);
-  c->ctx = ctx; c->kind = kind; c->part_rank = 0; c->part_world = 1;
+  c->ctx = ctx; c->kind = kind; c->part_rank = 0; c->part_world = 1;   // (uniforms start at 0, as GL's do: value-initialised)
   ctx->computes.push_back(c);
   *out = c;
   return TDT_OK;
@@ -1084,6 +1000,7 @@ int tdt_compute_create(tdt_ctx *ctx, int kind, tdt_compute **out) {
 
 void tdt_compute_destroy(tdt_compute *c) {
   if (!c) return;
+  if (c->ctx->multi) { tdt::multi_compute_destroy(c); return; }
   erase_from(c->ctx->computes, c);
   delete c;
 }
@@ -1102,6 +1019,7 @@ static int not_found(tdt_compute *c, const char *name, const char *type) {
 
 int tdt_set_i32(tdt_compute *c, const char *name, int32_t v) {
   if (!c) return TDT_ERR_INVALID_VALUE;
+  if (c->ctx->multi) return tdt::multi_set_i32(c, name, v);
   if (name && c->kind == TDT_PROGRAM_RAYTRACER) {
     if (!std::strcmp(name, "camera.image_width")) { c->image_width = v; return TDT_OK; }
     if (!std::strcmp(name, "camera.image_height")) { c->image_height = v; return TDT_OK; }
@@ -1118,6 +1036,7 @@ int tdt_set_f32(tdt_compute *c, const char *name, float) {
 
 int tdt_set_vec3f(tdt_compute *c, const char *name, float x, float y, float z) {
   if (!c) return TDT_ERR_INVALID_VALUE;
+  if (c->ctx->multi) return tdt::multi_set_vec3f(c, name, x, y, z);
   float *dst = nullptr;
   if (name && c->kind == TDT_PROGRAM_RAYTRACER) {
     if (!std::strcmp(name, "camera.horizontal")) dst = c->horizontal;
@@ -1139,11 +1058,11 @@ int tdt_buffer_create(tdt_ctx *ctx, const void *data, size_t bytes, tdt_buffer *
   if (!ctx || !out) return fail(ctx, TDT_ERR_INVALID_VALUE, "null argument");
   *out = nullptr;
   if (bytes && !data) return fail(ctx, TDT_ERR_INVALID_VALUE, "null data with non-zero size");
+  if (ctx->multi) return tdt::multi_buffer_create(ctx, data, bytes, out);
   tdt_buffer *b = new (std::nothrow) tdt_buffer();
   if (!b) return fail(ctx, TDT_ERR_HIP, "out of host memory");
   b->ctx = ctx; b->bytes = bytes; b->dev = nullptr;
-  static std::atomic<unsigned long long> next_version{1};   // contexts may live on different threads
-  b->version = next_version.fetch_add(1);
+  b->version = next_buffer_version();
   std::memset(b->shadow, 0, sizeof b->shadow);
   TDT_HIP(ctx, hipSetDevice(ctx->device));
   // 16 bytes of zero slack so that the widest load at the last valid dword stays inside the allocation
@@ -1161,6 +1080,7 @@ int tdt_buffer_create(tdt_ctx *ctx, const void *data, size_t bytes, tdt_buffer *
 
 void tdt_buffer_destroy(tdt_buffer *b) {
   if (!b) return;
+  if (b->ctx->multi) { tdt::multi_buffer_destroy(b); return; }
   tdt_ctx *ctx = b->ctx;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
@@ -1174,6 +1094,7 @@ void tdt_buffer_destroy(tdt_buffer *b) {
 int tdt_bind_buffer_base(tdt_ctx *ctx, int target, unsigned slot, tdt_buffer *b) {
   if (!ctx) return TDT_ERR_INVALID_VALUE;
   if (b && b->ctx != ctx) return fail(ctx, TDT_ERR_INVALID_OPERATION, "buffer belongs to another context");
+  if (ctx->multi) return tdt::multi_bind_buffer_base(ctx, target, slot, b);
   if (target == TDT_SHADER_STORAGE_BUFFER) {
     if (slot >= (unsigned)kNumSlots) return fail(ctx, TDT_ERR_INVALID_VALUE, "shader-storage slot out of range (0..7)");
     ctx->ssbo[slot] = b;
@@ -1189,6 +1110,7 @@ int tdt_bind_buffer_base(tdt_ctx *ctx, int target, unsigned slot, tdt_buffer *b)
 
 int tdt_buffer_read(tdt_buffer *b, size_t offset, size_t bytes, void *dst) {
   if (!b) return TDT_ERR_INVALID_VALUE;
+  if (b->ctx->multi) return b->replicas.empty() ? TDT_ERR_INVALID_VALUE : tdt_buffer_read(b->replicas[0], offset, bytes, dst);
   tdt_ctx *ctx = b->ctx;
   if (offset > b->bytes || bytes > b->bytes - offset) return fail(ctx, TDT_ERR_INVALID_VALUE, "read range outside the buffer");
   if (!bytes) return TDT_OK;
@@ -1201,6 +1123,7 @@ int tdt_buffer_read(tdt_buffer *b, size_t offset, size_t bytes, void *dst) {
 
 int tdt_buffer_sub_data(tdt_buffer *b, size_t offset, size_t bytes, const void *data) {
   if (!b) return TDT_ERR_INVALID_VALUE;
+  if (b->ctx->multi) return tdt::multi_buffer_sub_data(b, offset, bytes, data);
   tdt_ctx *ctx = b->ctx;
   if (offset > b->bytes || bytes > b->bytes - offset) return fail(ctx, TDT_ERR_INVALID_VALUE, "sub-data range outside the buffer");
   if (!bytes) return TDT_OK;
@@ -1220,6 +1143,7 @@ int tdt_image_create_rgba32f(tdt_ctx *ctx, int width, int height, tdt_image **ou
   if (!ctx || !out) return fail(ctx, TDT_ERR_INVALID_VALUE, "null argument");
   *out = nullptr;
   if (width <= 0 || height <= 0) return fail(ctx, TDT_ERR_INVALID_VALUE, "image size must be positive");
+  if (ctx->multi) return tdt::multi_image_create(ctx, nullptr, width, height, out);
   tdt_image *img = new (std::nothrow) tdt_image();
   if (!img) return fail(ctx, TDT_ERR_HIP, "out of host memory");
   img->ctx = ctx; img->w = width; img->h = height; img->owned = true; img->dev = nullptr;
@@ -1238,6 +1162,7 @@ int tdt_image_wrap_device(tdt_ctx *ctx, void *device_ptr, int width, int height,
   *out = nullptr;
   if (!device_ptr || width <= 0 || height <= 0) return fail(ctx, TDT_ERR_INVALID_VALUE, "bad device pointer or size");
   if (((uintptr_t)device_ptr & 15) != 0) return fail(ctx, TDT_ERR_INVALID_VALUE, "image memory must be 16-byte aligned");
+  if (ctx->multi) return tdt::multi_image_create(ctx, device_ptr, width, height, out);
   tdt_image *img = new (std::nothrow) tdt_image();
   if (!img) return fail(ctx, TDT_ERR_HIP, "out of host memory");
   img->ctx = ctx; img->w = width; img->h = height; img->owned = false; img->dev = (float *)device_ptr;
@@ -1248,6 +1173,7 @@ int tdt_image_wrap_device(tdt_ctx *ctx, void *device_ptr, int width, int height,
 
 void tdt_image_destroy(tdt_image *img) {
   if (!img) return;
+  if (img->ctx->multi) { tdt::multi_image_destroy(img); return; }
   tdt_ctx *ctx = img->ctx;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
@@ -1271,6 +1197,7 @@ void *tdt_image_device_ptr(const tdt_image *img) { return img ? img->dev : nullp
 
 int tdt_image_read(tdt_image *img, float *dst) {
   if (!img || !dst) return TDT_ERR_INVALID_VALUE;
+  if (img->ctx->multi) return tdt_image_read(img->full, dst);
   tdt_ctx *ctx = img->ctx;
   TDT_HIP(ctx, hipSetDevice(ctx->device));
   TDT_HIP(ctx, hipMemcpyAsync(dst, img->dev, (size_t)img->w * img->h * 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -1280,13 +1207,13 @@ int tdt_image_read(tdt_image *img, float *dst) {
 
 int tdt_image_read_rgba8(tdt_image *img, int top_down, uint8_t *dst) {
   if (!img || !dst) return TDT_ERR_INVALID_VALUE;
+  if (img->ctx->multi) return tdt_image_read_rgba8(img->full, top_down, dst);
   tdt_ctx *ctx = img->ctx;
   TDT_HIP(ctx, hipSetDevice(ctx->device));
   const size_t bytes = (size_t)img->w * img->h * 4;
   if (ctx->present_bytes < bytes) {
     if (ctx->present) (void)hipFree(ctx->present);
-  if (ctx->frame_carry) (void)hipFree(ctx->frame_carry);
-    ctx->present = nullptr; ctx->present_bytes = 0; ctx->frame_carry = nullptr; ctx->frame_carry_bytes = 0; ctx->probe_launch = false;
+    ctx->present = nullptr; ctx->present_bytes = 0;
     TDT_HIP(ctx, hipMalloc((void **)&ctx->present, bytes));
     ctx->present_bytes = bytes;
   }
@@ -1298,32 +1225,16 @@ int tdt_image_read_rgba8(tdt_image *img, int top_down, uint8_t *dst) {
   return TDT_OK;
 }
 
-static int launch_update(tdt_compute *c, int width, int height, int depth) {
-  tdt_ctx *ctx = c->ctx;
-  static const int required[] = {TDT_SLOT_CELLS, TDT_SLOT_DELTA, TDT_SLOT_OCTREE_FLOATS, TDT_SLOT_OCTREE_INTS};
-  for (int s : required)
-    if (!ctx->ssbo[s]) return fail(ctx, TDT_ERR_INCOMPLETE, "no buffer bound to shader-storage slot " + std::to_string(s));
-  if (!ctx->atomic0 || ctx->atomic0->bytes < 4) return fail(ctx, TDT_ERR_INCOMPLETE, "no atomic-counter buffer bound to slot 0");
-  if (ctx->ssbo[TDT_SLOT_OCTREE_FLOATS]->bytes < 28 || ctx->ssbo[TDT_SLOT_OCTREE_INTS]->bytes < 12)
-    return fail(ctx, TDT_ERR_INVALID_VALUE, "octree uniform buffers are too small (need 28 / 12 bytes)");
-  float of[7]; int32_t oi[3];
-  std::memcpy(of, ctx->ssbo[TDT_SLOT_OCTREE_FLOATS]->shadow, sizeof of);
-  std::memcpy(oi, ctx->ssbo[TDT_SLOT_OCTREE_INTS]->shadow, sizeof oi);
-  // ComputeShader::dispatch_compute with group_size {1,1,1}: groups = max(dim / 1, 1) (compute_shader.rs:30-32)
-  const int gx = width < 1 ? 1 : width, gy = height < 1 ? 1 : height, gz = depth < 1 ? 1 : depth;
-  tdt_buffer *cells = ctx->ssbo[TDT_SLOT_CELLS], *delta = ctx->ssbo[TDT_SLOT_DELTA];
-  auto dwords = [](const tdt_buffer *b) { size_t d = b->bytes >> 2; return (uint32_t)(d > 0xFFFFFFFFull ? 0xFFFFFFFFull : d); };
-  TDT_HIP(ctx, hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(tdt::octree_update_kernel, dim3(1), dim3(64), 0, ctx->stream, (uint32_t *)cells->dev, dwords(cells),
-                     (const uint32_t *)delta->dev, dwords(delta), of[6], oi[0], oi[2], (uint32_t *)ctx->atomic0->dev, gx, gy, gz);
-  TDT_HIP(ctx, hipGetLastError());
-  cells->version += 0x100000000ull;      // the trace's LDS-table image / scan of this buffer are stale now
-  return TDT_OK;
+// events around the launches of a frame (only when tdt_debug_phase_timing switched them on)
+static void phase_mark(tdt_ctx *ctx, int i) {
+  if (!ctx->phase_timing) return;
+  if (hipEventRecord(ctx->phase_ev[i], ctx->stream) == hipSuccess) ctx->phase_n = i + 1;
 }
 
 int tdt_dispatch_compute(tdt_compute *c, int width, int height, int depth) {
   if (!c) return TDT_ERR_INVALID_VALUE;
-  if (c->kind == TDT_PROGRAM_OCTREE_UPDATE) return launch_update(c, width, height, depth);
+  if (c->ctx->multi) return tdt::multi_dispatch_compute(c, width, height, depth);
+  if (c->kind == TDT_PROGRAM_OCTREE_UPDATE) return tdt::launch_update(c, width, height, depth);
   // A frame whose inputs differ from what the recorded pixel costs were measured on (first frame, moved camera, edited
   // scene) is traced in two phases: spp/16 probe samples per pixel in image (or tile-sum) order, then — the launch below
   // sees identical inputs and fresh costs — the rest in the per-pixel cost order of THIS frame's probe, and a resolve.  Running
@@ -1337,9 +1248,9 @@ int tdt_dispatch_compute(tdt_compute *c, int width, int height, int depth) {
   if (ready && ctx->ssbo[TDT_SLOT_OCTREE_FLOATS]->bytes >= 28 && ctx->ssbo[TDT_SLOT_OCTREE_INTS]->bytes >= 12) {
     const Cover k = cover_of(c, width, height);
     const Tiles t = tiles_of(c, k);
-    unsigned char sig[sizeof ctx->cost_sig];
-    make_sig(ctx, c, k, ctx->image0, sig);
-    const bool replay = ctx->cost_tiles == (uint32_t)t.owned && std::memcmp(sig, ctx->cost_sig, sizeof sig) == 0;
+    CostSig sig;
+    make_sig(ctx, c, k, ctx->image0, &sig);
+    const bool replay = ctx->cost_tiles == (uint32_t)t.owned && std::memcmp(&sig, &ctx->cost_sig, sizeof sig) == 0;
     if (!replay && t.owned > 0) {
       TDT_HIP(ctx, hipSetDevice(ctx->device));
       const size_t px = (size_t)ctx->image0->w * (size_t)ctx->image0->h, slots = (size_t)t.owned * 1024;
@@ -1352,18 +1263,26 @@ int tdt_dispatch_compute(tdt_compute *c, int width, int height, int depth) {
       }
       const int probe = spp / 16;                    // measured: 1/8 and 1/32 are 0-3 % slower, 1/64 5 %
       ctx->probe_launch = true;
+      phase_mark(ctx, 0);
       int rc = launch(c, width, height, depth, 1, 0, probe, ctx->frame_carry, 0, nullptr);
       ctx->probe_launch = false;
+      phase_mark(ctx, 1);
       if (rc == TDT_OK) rc = launch(c, width, height, depth, 1, probe, spp - probe, ctx->frame_carry, 0, nullptr);
+      phase_mark(ctx, 2);
       if (rc == TDT_OK) rc = launch(c, width, height, depth, 2, 0, 0, nullptr, spp, nullptr);
+      phase_mark(ctx, 3);
       return rc;
     }
   }
-  return launch(c, width, height, depth, 0, 0, spp, nullptr, spp, nullptr);
+  phase_mark(ctx, 0);
+  const int rc = launch(c, width, height, depth, 0, 0, spp, nullptr, spp, nullptr);
+  phase_mark(ctx, 1);
+  return rc;
 }
 
 int tdt_set_partition(tdt_compute *c, int rank, int world) {
   if (!c) return TDT_ERR_INVALID_VALUE;
+  if (c->ctx->multi) return fail(c->ctx, TDT_ERR_INVALID_OPERATION, "a multi-device context partitions the image over its devices itself");
   if (world < 1 || rank < 0 || rank >= world) return fail(c->ctx, TDT_ERR_INVALID_VALUE, "need 0 <= rank < world");
   c->part_rank = rank; c->part_world = world;
   return TDT_OK;
@@ -1371,6 +1290,7 @@ int tdt_set_partition(tdt_compute *c, int rank, int world) {
 
 int tdt_dispatch_accumulate(tdt_compute *c, int width, int height, int depth, int spp_begin, int spp_count, void *carry) {
   if (!c) return TDT_ERR_INVALID_VALUE;
+  if (c->ctx->multi) return fail(c->ctx, TDT_ERR_INVALID_OPERATION, "progressive passes are a single-device feature (per-device carry memory)");
   if (c->kind != TDT_PROGRAM_RAYTRACER) return fail(c->ctx, TDT_ERR_INVALID_OPERATION, "not the raytracer program");
   if (spp_begin < 0 || spp_count < 0) return fail(c->ctx, TDT_ERR_INVALID_VALUE, "negative sample range");
   if (carry && ((uintptr_t)carry & 15) != 0) return fail(c->ctx, TDT_ERR_INVALID_VALUE, "carry memory must be 16-byte aligned");
@@ -1379,6 +1299,7 @@ int tdt_dispatch_accumulate(tdt_compute *c, int width, int height, int depth, in
 
 int tdt_dispatch_resolve(tdt_compute *c, int width, int height, int depth, int total_spp) {
   if (!c) return TDT_ERR_INVALID_VALUE;
+  if (c->ctx->multi) return fail(c->ctx, TDT_ERR_INVALID_OPERATION, "progressive passes are a single-device feature (per-device carry memory)");
   if (c->kind != TDT_PROGRAM_RAYTRACER) return fail(c->ctx, TDT_ERR_INVALID_OPERATION, "not the raytracer program");
   return launch(c, width, height, depth, 2, 0, 0, nullptr, total_spp, nullptr);
 }
@@ -1401,10 +1322,48 @@ int tdt_owned_tiles(const tdt_compute *c, int width, int height, int depth, int 
 
 int tdt_dispatch_counted(tdt_compute *c, int width, int height, int depth, uint64_t counts[8]) {
   if (!c || !counts) return TDT_ERR_INVALID_VALUE;
+  if (c->ctx->multi) return tdt::multi_dispatch_counted(c, width, height, depth, counts);
   if (c->kind != TDT_PROGRAM_RAYTRACER) return fail(c->ctx, TDT_ERR_INVALID_OPERATION, "not the raytracer program");
   static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "");
   return launch(c, width, height, depth, 0, 0, c->samples_per_pixel, nullptr, c->samples_per_pixel,
                 reinterpret_cast<unsigned long long *>(counts));
+}
+
+int tdt_dispatch_counted_range(tdt_compute *c, int width, int height, int depth, int spp_begin, int spp_count, void *carry,
+                               uint64_t counts[8]) {
+  if (!c || !counts) return TDT_ERR_INVALID_VALUE;
+  if (c->ctx->multi) return fail(c->ctx, TDT_ERR_INVALID_OPERATION, "progressive passes are a single-device feature (per-device carry memory)");
+  if (c->kind != TDT_PROGRAM_RAYTRACER) return fail(c->ctx, TDT_ERR_INVALID_OPERATION, "not the raytracer program");
+  if (spp_begin < 0 || spp_count < 0) return fail(c->ctx, TDT_ERR_INVALID_VALUE, "negative sample range");
+  if (carry && ((uintptr_t)carry & 15) != 0) return fail(c->ctx, TDT_ERR_INVALID_VALUE, "carry memory must be 16-byte aligned");
+  return launch(c, width, height, depth, 1, spp_begin, spp_count, carry, 0, reinterpret_cast<unsigned long long *>(counts));
+}
+
+int tdt_forget_costs(tdt_ctx *ctx) {
+  if (!ctx) return TDT_ERR_INVALID_VALUE;
+  if (ctx->multi) return tdt::multi_forget_costs(ctx);
+  ctx->cost_tiles = 0; ctx->cost_dispatches = 0;      // launch(): "no usable history" -> image order, fresh cost arrays
+  return TDT_OK;
+}
+
+int tdt_debug_phase_timing(tdt_ctx *ctx, int enable, float ms[3]) {
+  if (!ctx) return TDT_ERR_INVALID_VALUE;
+  TDT_HIP(ctx, hipSetDevice(ctx->device));
+  if (ms) {
+    ms[0] = ms[1] = ms[2] = 0.f;
+    if (ctx->phase_timing && ctx->phase_n >= 2) {
+      TDT_HIP(ctx, hipEventSynchronize(ctx->phase_ev[ctx->phase_n - 1]));
+      for (int i = 0; i + 1 < ctx->phase_n; i++) TDT_HIP(ctx, hipEventElapsedTime(&ms[ctx->phase_n == 2 ? 1 : i], ctx->phase_ev[i], ctx->phase_ev[i + 1]));
+    }
+  }
+  if (enable && !ctx->phase_timing) {
+    for (auto &e : ctx->phase_ev) TDT_HIP(ctx, hipEventCreate(&e));
+    ctx->phase_timing = true; ctx->phase_n = 0;
+  } else if (!enable && ctx->phase_timing) {
+    for (auto &e : ctx->phase_ev) (void)hipEventDestroy(e);
+    ctx->phase_timing = false; ctx->phase_n = 0;
+  }
+  return TDT_OK;
 }
 
 /* lane-utilisation diagnostics of the last tdt_dispatch_counted on this context (see Counters) */

@@ -28,6 +28,8 @@ _P, _I, _U, _F, _S = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_floa
 _PP = ctypes.POINTER(ctypes.c_void_p)
 SYMBOLS = [
     ("tdt_ctx_create", _I, [_I, _P, _PP]),
+    ("tdt_ctx_create_multi", _I, [_I, ctypes.POINTER(ctypes.c_int), _PP]),
+    ("tdt_ctx_device_count", _I, [_P]),
     ("tdt_ctx_destroy", None, [_P]),
     ("tdt_finish", _I, [_P]),
     ("tdt_last_error", ctypes.c_char_p, [_P]),
@@ -61,6 +63,16 @@ SYMBOLS = [
     ("tdt_owned_tiles", _I, [_P, _I, _I, _I, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     ("tdt_assemble_tiles", _I, [_P, _P, _I, _I, _P, _I, _I, _I]),
     ("tdt_dispatch_counted", _I, [_P, _I, _I, _I, ctypes.POINTER(ctypes.c_uint64)]),
+    ("tdt_dispatch_counted_range", _I, [_P, _I, _I, _I, _I, _I, _P, ctypes.POINTER(ctypes.c_uint64)]),
+    ("tdt_forget_costs", _I, [_P]),
+    ("tdt_debug_phase_timing", _I, [_P, _I, ctypes.POINTER(ctypes.c_float)]),
+    ("tdt_debug_multi_timing", _I, [_P, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
+    ("tdt_debug_multi_transport", ctypes.c_char_p, [_P]),
+    ("tdt_octree_build_cells", _I, [_P, _P, _S, _I, _PP, ctypes.POINTER(ctypes.c_uint32)]),
+    ("tdt_octree_build_from_points", _I, [_P, _P, _S, ctypes.POINTER(ctypes.c_int32), _P, _P, _S, _I, _I, _PP,
+                                          ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
+    ("tdt_debug_edit_mode", _I, [_P, _I]),
+    ("tdt_debug_last_edit_path", _I, [_P]),
     ("tdt_debug_counters", _I, [_P, ctypes.POINTER(ctypes.c_uint64)]),
     ("tdt_debug_wave_ends", _I, [_P, ctypes.POINTER(ctypes.c_uint64), _I]),
     ("tdt_debug_pixel_log", _I, [_P, ctypes.c_void_p, ctypes.c_size_t]),
@@ -103,13 +115,51 @@ class TdtError(RuntimeError):
 class Context:
     """The GL context of main.rs:58-61,108-112: one HIP device + stream."""
 
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, devices=None):
+        """devices = [ids]: ONE context over several GPUs (tdt_ctx_create_multi): uploads replicate, a raytracer dispatch is
+        sharded over the devices and gathered + assembled on the first; otherwise a single-device context."""
         h = ctypes.c_void_p()
-        rc = lib().tdt_ctx_create(int(device), ctypes.c_void_p(stream) if stream else None, ctypes.byref(h))
+        if devices is not None:
+            ids = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+            rc = lib().tdt_ctx_create_multi(len(devices), ids, ctypes.byref(h))
+            device = devices[0] if len(devices) else 0
+        else:
+            rc = lib().tdt_ctx_create(int(device), ctypes.c_void_p(stream) if stream else None, ctypes.byref(h))
         if rc != OK:
             raise TdtError(rc, lib().tdt_last_error(None).decode())
         self.h = h
         self.device = device
+
+    def device_count(self):
+        return int(lib().tdt_ctx_device_count(self.h))
+
+    def forget_costs(self):
+        """Drop the per-pixel cost history: the next dispatch_compute is scheduled like a context's first frame."""
+        self.check(lib().tdt_forget_costs(self.h))
+
+    def phase_timing(self, enable=True):
+        """(probe_ms, main_ms, resolve_ms) of the last dispatch_compute (blocks); switches the recording on / off."""
+        ms = (ctypes.c_float * 3)()
+        self.check(lib().tdt_debug_phase_timing(self.h, 1 if enable else 0, ms))
+        return tuple(float(v) for v in ms)
+
+    def multi_timing(self):
+        """Multi-device context: ([trace ms per device], gather ms, assemble ms) of the last raytracer dispatch (blocks)."""
+        n = self.device_count()
+        tr, g, a = (ctypes.c_float * n)(), ctypes.c_float(), ctypes.c_float()
+        self.check(lib().tdt_debug_multi_timing(self.h, tr, ctypes.byref(g), ctypes.byref(a)))
+        return [float(v) for v in tr], float(g.value), float(a.value)
+
+    def multi_transport(self):
+        return lib().tdt_debug_multi_transport(self.h).decode()
+
+    def edit_mode(self, mode):
+        """0: edits run in parallel when that is provably the ordered result; 1: always the ordered one-lane walk."""
+        self.check(lib().tdt_debug_edit_mode(self.h, mode))
+
+    def last_edit_path(self):
+        """1 = the last edit dispatch took the ordered walk, 2 = the parallel form, 0 = none yet."""
+        return int(lib().tdt_debug_last_edit_path(self.h))
 
     def check(self, rc):
         if rc != OK:
@@ -148,6 +198,12 @@ class VertexBufferObject:
         h = ctypes.c_void_p()
         ctx.check(lib().tdt_buffer_create(ctx.h, a.ctypes.data if a.size else None, a.nbytes, ctypes.byref(h)))
         self.ctx, self.h, self.nbytes = ctx, h, a.nbytes
+
+    @classmethod
+    def _adopt(cls, ctx, h, nbytes):
+        b = cls.__new__(cls)
+        b.ctx, b.h, b.nbytes = ctx, h, nbytes
+        return b
 
     def sub_data(self, offset, data):
         a = np.ascontiguousarray(data)
@@ -297,6 +353,39 @@ class ComputeShader:
         self.ctx.check(lib().tdt_dispatch_counted(self.h, width, height, depth, c))
         return dict(zip(self.COUNT_FIELDS, [int(v) for v in c]))
 
+    def dispatch_counted_range(self, width, height, depth, spp_begin, spp_count, carry_ptr=None):
+        """dispatch_accumulate, instrumented: the events of ONE launch of a progressive / two-phase frame."""
+        c = (ctypes.c_uint64 * 8)()
+        self.ctx.check(lib().tdt_dispatch_counted_range(self.h, width, height, depth, spp_begin, spp_count,
+                                                        ctypes.c_void_p(carry_ptr) if carry_ptr else None, c))
+        return dict(zip(self.COUNT_FIELDS, [int(v) for v in c]))
+
+
+def octree_build_cells(ctx, voxels_xyzm, depth):
+    """SURVEY §8f-1 on the GPU (tdt_octree_build_cells): (n, 4) int32 voxels {x, y, z, material + 1} in grid coordinates ->
+    (cells VertexBufferObject, number of cells)."""
+    v = np.ascontiguousarray(voxels_xyzm, np.int32).reshape(-1, 4)
+    h, n = ctypes.c_void_p(), ctypes.c_uint32(0)
+    ctx.check(lib().tdt_octree_build_cells(ctx.h, v.ctypes.data if v.size else None, v.shape[0], depth, ctypes.byref(h), ctypes.byref(n)))
+    return VertexBufferObject._adopt(ctx, h, int(n.value) * 64), int(n.value)
+
+
+def octree_build_from_points(ctx, voxels_xyzk, min_point, palette_keys, palette_rgb, z_up=True, max_iter=256):
+    """tdt_scene_from_ply on the GPU (tdt_octree_build_from_points): PlyFileContent{voxels, albedos, min_point}
+    (ply_point_loader.rs:84-93) -> ({slot: VertexBufferObject} for slots 0,1,2,3,4,6,7 — not bound —, max_depth, cell_count)."""
+    v = np.ascontiguousarray(voxels_xyzk, np.int32).reshape(-1, 4)
+    keys = np.ascontiguousarray(palette_keys, np.uint32)
+    rgb = np.ascontiguousarray(palette_rgb, np.uint8).reshape(-1, 3)
+    mp = (ctypes.c_int32 * 3)(*[int(x) for x in min_point])
+    out = (ctypes.c_void_p * 8)()
+    depth, cc = ctypes.c_int32(0), ctypes.c_int32(0)
+    ctx.check(lib().tdt_octree_build_from_points(ctx.h, v.ctypes.data, v.shape[0], mp, keys.ctypes.data, rgb.ctypes.data, keys.size,
+                                                 1 if z_up else 0, max_iter, out, ctypes.byref(depth), ctypes.byref(cc)))
+    vbos = {}
+    for slot in (0, 1, 2, 3, 4, 6, 7):
+        vbos[slot] = VertexBufferObject._adopt(ctx, ctypes.c_void_p(out[slot]), 0)
+    return vbos, int(depth.value), int(cc.value)
+
 
 def initial_uniforms(camera, program):
     """camera.rs:241-253: sends all eight camera uniforms."""
@@ -338,13 +427,14 @@ class Renderer:
     """Convenience wrapper used by tests, smoke() and bench.py: a context with one scene, one
     camera and one image, i.e. the state main.rs has built when it reaches its render loop."""
 
-    def __init__(self, scene, camera, device=0, stream=None, rank=0, world=1, image_ptr=None, tile_buffer_tiles=None):
-        self.ctx = Context(device, stream)
+    def __init__(self, scene, camera, device=0, stream=None, rank=0, world=1, image_ptr=None, tile_buffer_tiles=None, devices=None):
+        self.ctx = Context(device, stream, devices=devices)
         self.shader = ComputeShader(self.ctx)
         self.vbos = upload_scene(self.ctx, scene)
         self.camera = camera
         initial_uniforms(camera, self.shader.program)
-        self.shader.set_partition(rank, world)
+        if devices is None:
+            self.shader.set_partition(rank, world)
         if tile_buffer_tiles is not None:      # this rank's tile buffer [k][32][32] RGBA
             w, rows = 32, 32 * tile_buffer_tiles
         else:
