@@ -1,18 +1,27 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path: one step = one ComputeShader::dispatch_compute(W+1, H+1, 1) of the
-voxel path trace over a synthetic scene already resident in HBM (plus, for N > 1 GPUs, the single
-RCCL gather of per-rank tile buffers and their de-interleave on rank 0).
+"""Benchmark of the hot path: one step = one ComputeShader::dispatch_compute(W+1, H+1, 1) of the voxel path trace over a
+synthetic scene already resident in HBM (plus, for N > 1 GPUs, the single RCCL gather of per-rank tile buffers and their
+de-interleave on rank 0).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|5] [--spp S] [--scaling weak|strong]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5] [--spp S] [--scaling weak|strong]
 
-N = 1 workload (default): BASELINE.json's metric configuration — 1920x1080, 64 spp, max_bounce 8,
-the 64^3-octree synthetic scene of configs[1] — dispatched exactly as the reference does
-(main.rs:579), so 1056 of the 1080 rows are written (compute_shader.rs:30-32) and only written
-pixels are counted.  Prints ONE JSON line on rank 0.
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches its N ranks itself (child processes,
+started before this process touches a GPU); under `python -m torch.distributed.run --nproc-per-node N` it is one of the ranks.
+
+N = 1 workload (default): BASELINE.json's metric configuration — 1920x1080, 64 spp, max_bounce 8, the 64^3-octree synthetic
+scene of configs[1] — dispatched exactly as the reference does (main.rs:579), so 1056 of the 1080 rows are written
+(compute_shader.rs:30-32) and only written pixels are counted.  Every timed step is a frame the scheduler has NOT seen
+(tdt_forget_costs before it: two-phase schedule, probe in image order); the replay of an identical frame is reported beside
+it as config.replay_ms.  N > 1: weak scaling of that frame (N x the pixel rows over the same frustum).  Every line also
+carries a `strong` block — BASELINE configs[3]: ONE 7680x4320 / 64 spp / 256^3 frame sharded over the N ranks, per-rank trace,
+gather and assemble times separated — and a `single_process` block: the same 8K frame driven through the C ABI's
+multi-device context (tdt_ctx_create_multi) from one process.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,32 +31,364 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md chip table
 
 WORKLOADS = {
-    # config id -> (W, H, spp, max_bounce, description)
-    2: (1920, 1080, 64, 8, "1920x1080, 64 spp, max_bounce 8, 64^3 octree terrain+spheres (BASELINE configs[1] scene at the metric's 64 spp)"),
-    3: (3840, 2160, 64, 16, "3840x2160, 64 spp, max_bounce 16, 256^3 octree (BASELINE configs[2])"),
-    5: (1920, 1080, 64, 8, "1920x1080, 64 spp pass of the progressive config, max_bounce 8, 512^3 sparse octree (BASELINE configs[4])"),
+    # config id -> (W, H, spp, max_bounce, description, scene config)
+    2: (1920, 1080, 64, 8, "1920x1080, 64 spp, max_bounce 8, 64^3 octree terrain+spheres (BASELINE configs[1] scene at the metric's 64 spp)", 2),
+    3: (3840, 2160, 64, 16, "3840x2160, 64 spp, max_bounce 16, 256^3 octree (BASELINE configs[2])", 3),
+    4: (7680, 4320, 64, 8, "7680x4320, 64 spp, max_bounce 8, 256^3 octree, ONE frame tile-sharded over the ranks (BASELINE configs[3])", 4),
+    5: (1920, 1080, 64, 8, "1920x1080, 64 spp pass of the progressive config, max_bounce 8, 512^3 sparse octree (BASELINE configs[4])", 5),
 }
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=None)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="N>1: weak = N x the pixel rows over the same frustum (per-GPU work fixed); strong = same image")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="N>1: weak = N x the pixel rows over the same frustum (per-GPU work fixed; default); strong = same image "
+                         "(always strong for --config 4)")
     ap.add_argument("--passes", type=int, default=1,
                     help="N=1 only: a step = one PROGRESSIVE frame of passes x spp samples per pixel (configs[4] is 16 x 64): "
                          "running sums and hit-record carry through HBM, one resolve at the end (bit-identical to one pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaled 8K block (BASELINE configs[3])")
+    ap.add_argument("--no-single-process", action="store_true", help="skip the multi-device-context (one process, N GPUs) block")
+    ap.add_argument("--strong-steps", type=int, default=3)
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="torch.distributed backend of the N>1 gather; gloo (through host memory) lets several ranks share "
                          "one GPU to rehearse the multi-rank path on a single-GPU box")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N>1 code path (tile buffer, RCCL gather, de-interleave) even with one rank: a self-test")
-    args = ap.parse_args()
+    ap.add_argument("--replay", action="store_true", help="headline = replay of an identical frame (round-1 behaviour)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="self-check of the launch path without a GPU: the ranks meet over gloo, sum their ranks, rank 0 prints a JSON line")
+    ap.add_argument("--single-process-leg", type=int, default=0, metavar="N",
+                    help="(internal) run ONLY the multi-device-context measurement over N devices and print its JSON")
+    ap.add_argument("--share-device", action="store_true",
+                    help="single-process leg: all N shares on device 0 (one-GPU box rehearsal; peer-copy transport)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------ self-launch -----
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def rank_environments(n, port, base=None):
+    """The environment torch.distributed.run would give each of n ranks on one node."""
+    envs = []
+    for r in range(n):
+        e = dict(base if base is not None else os.environ)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                 MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=e.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        envs.append(e)
+    return envs
+
+
+def self_launch(argv, n):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as fresh child processes (this process has not
+    touched a GPU and never will), pass rank 0's JSON line through, exit with the worst return code."""
+    envs = rank_environments(n, free_port())
+    procs = []
+    for r, e in enumerate(envs):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rc = rc or 1
+        rc = rc or p.returncode
+    line = ""
+    for ln in (out or "").splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if line:
+        print(line, flush=True)
+    elif not rc:
+        rc = 1
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ helpers ---------
+def algorithmic_bytes(counts):
+    """8 B per Node load + material / albedo / attribute reads + 40 B of octree uniforms; 16 B written per pixel."""
+    read = 8 * counts["node_loads"] + 24 * counts["lambertian"] + 28 * counts["metal"] + 16 * counts["dielectric"] + 40
+    return int(read), int(16 * counts["pixels"])
+
+
+def quoted(path, key):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", path))).get(key)
+    except Exception:
+        return None
+
+
+def single_process_leg(args):
+    """One process, N devices, through tdt_ctx_create_multi: the 8K frame of BASELINE configs[3] (or --config)."""
+    import numpy as np
+    import torch
+    from tdt4230_project_raytracing_amd import host, rt
+    n = args.single_process_leg
+    cfg = args.config if args.config != 2 else 4
+    W, H, spp, bounce, desc, scene_cfg = WORKLOADS[cfg]
+    if args.spp:
+        spp = args.spp
+    have = torch.cuda.device_count()
+    devices = [0] * n if args.share_device else list(range(n))
+    if not args.share_device and have < n:
+        raise SystemExit(f"single-process leg over {n} devices, but {have} are visible")
+    scene = host.Scene.config(scene_cfg)
+    cam = host.camera_reference_pose(W, H, spp, bounce)
+    r = rt.Renderer(scene, cam, devices=devices)
+    dw, dh = W + 1, H + 1
+    px = r.shader.covered_pixels(dw, dh)
+    for _ in range(max(1, args.warmup)):
+        r.ctx.forget_costs()
+        r.dispatch()
+    r.ctx.finish()
+    rows = []
+    t0 = time.perf_counter()
+    for _ in range(args.strong_steps):
+        r.ctx.forget_costs()
+        r.dispatch()
+        rows.append(r.ctx.multi_timing())                 # blocks until the frame is assembled
+    dt = (time.perf_counter() - t0) / args.strong_steps
+    # the assembled frame, checked on three 4-row bands against a single-device trace of the same rows' work-groups is
+    # the job of tests/test_gpu_multi.py; here: the whole covered image was written
+    img = r.texture.read()
+    written = int((img[..., 3] == 1).sum())
+    out = {"devices": devices, "transport": r.ctx.multi_transport(), "workload": desc, "image": [W, H], "spp": spp,
+           "written_pixels": written, "covered_pixels": px, "steps": args.strong_steps, "ms_per_frame": round(dt * 1e3, 3),
+           "value": round(px * spp / dt / 1e6, 2), "unit": "Mray-samples/s",
+           "trace_ms_per_device": [round(float(np.mean([row[0][i] for row in rows])), 3) for i in range(n)],
+           "gather_ms": round(float(np.mean([row[1] for row in rows])), 3),
+           "assemble_ms": round(float(np.mean([row[2] for row in rows])), 3),
+           "schedule": "every frame history-free (tdt_forget_costs): two-phase on each device"}
+    r.close()
+    print(json.dumps(out), flush=True)
+
+
+def run_single_process_child(args, n, timeout_s=240):
+    """The multi-device-context leg in a fresh process (isolated: a failure there is reported, not fatal)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--single-process-leg", str(n), "--strong-steps", str(args.strong_steps),
+           "--warmup", "1"]
+    if args.config == 4 and args.spp:
+        cmd += ["--spp", str(args.spp)]
+    if args.backend == "gloo":
+        cmd += ["--share-device"]                          # the one-GPU rehearsal: all shares on device 0
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                           "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": f"timed out after {timeout_s} s"}
+    for ln in reversed(p.stdout.splitlines()):
+        if ln.startswith("{"):
+            try:
+                return json.loads(ln)
+            except ValueError:
+                break
+    return {"error": f"rc {p.returncode}: " + (p.stderr or p.stdout)[-400:]}
+
+
+def rendezvous_only():
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank), 1.0], dtype=torch.float64)
+    dist.all_reduce(t)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"rendezvous": world, "rank_sum": t[0].item(), "ranks_seen": int(t[1].item())}), flush=True)
+
+
+# ------------------------------------------------------------------------------------------------ a rank ----------
+class Rank:
+    """One rank's state: device, stream, process group."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the trace has no CPU path")
+        if args.backend == "gloo":
+            local_rank %= torch.cuda.device_count()              # rehearsal: ranks may share a device
+        torch.cuda.set_device(local_rank)
+        self.local_rank = local_rank
+        self.dev = torch.device("cuda", local_rank)
+        self.backend = args.backend
+        self.sharded = self.world > 1 or args.force_dist
+        if self.sharded:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            else:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+        self.stream = torch.cuda.Stream(device=self.dev)
+
+    def fence(self):
+        if self.sharded:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def reduce(self, values, op):
+        """all-reduce a short list of floats over the ranks (max / sum)."""
+        if not self.sharded:
+            return list(values)
+        t = self.torch.tensor(list(values), dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM)
+        return [float(v) for v in t]
+
+    def gather_floats(self, value):
+        """every rank's float, on every rank"""
+        if not self.sharded:
+            return [float(value)]
+        t = self.torch.zeros(self.world, dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        t[self.rank] = value
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [float(v) for v in t]
+
+    def close(self):
+        if self.sharded:
+            self.dist.destroy_process_group()
+
+
+class Workload:
+    """One scene + camera + image on a rank: a whole image (unsharded) or this rank's tile buffer + gather + assemble."""
+
+    def __init__(self, R, cfg, spp=None, rows_factor=1, passes=1):
+        import numpy as np  # noqa: F401
+        from tdt4230_project_raytracing_amd import host, rt
+        torch = R.torch
+        self.R, self.rt = R, rt
+        W, H, wspp, bounce, desc, scene_cfg = WORKLOADS[cfg]
+        self.cfg, self.desc, self.bounce = cfg, desc, bounce
+        self.spp = spp or wspp
+        self.passes = passes
+        self.scene = host.Scene.config(scene_cfg)
+        self.cam = host.camera_reference_pose(W, H, self.spp, bounce)
+        self.rows_factor = rows_factor
+        if rows_factor > 1:
+            # same frustum, rows_factor x the pixel rows: every rank keeps one N=1 frame's worth of work
+            self.cam.image_height = H * rows_factor
+        self.IW, self.IH = self.cam.image_width, self.cam.image_height
+        self.dw, self.dh = self.IW + 1, self.IH + 1                      # main.rs:579
+        IW, IH, dw, dh = self.IW, self.IH, self.dw, self.dh
+        with torch.cuda.stream(R.stream):
+            self.full = torch.zeros((IH, IW, 4), dtype=torch.float32, device=R.dev) if R.rank == 0 else None
+            if not R.sharded:
+                self.r = rt.Renderer(self.scene, self.cam, device=R.local_rank, stream=R.stream.cuda_stream, image_ptr=self.full.data_ptr())
+                self.tiles_per_rank = 0
+                self.tile_buf = self.gathered = self.full_tex = None
+            else:
+                cover_w = min(max(dw // 32, 1) * 32, IW)
+                cover_h = min(max(dh // 32, 1) * 32, IH)
+                total_tiles = -(-cover_w // 32) * -(-cover_h // 32)
+                self.tiles_per_rank = -(-total_tiles // R.world)                # what rank 0 owns: the most
+                self.tile_buf = torch.zeros((self.tiles_per_rank, 32, 32, 4), dtype=torch.float32, device=R.dev)
+                self.r = rt.Renderer(self.scene, self.cam, device=R.local_rank, stream=R.stream.cuda_stream, rank=R.rank, world=R.world,
+                                     image_ptr=self.tile_buf.data_ptr(), tile_buffer_tiles=self.tiles_per_rank)
+                self.gathered = torch.zeros((R.world, self.tiles_per_rank, 32, 32, 4), dtype=torch.float32, device=R.dev) if R.rank == 0 else None
+                self.full_tex = rt.Texture.wrap_device(self.r.ctx, self.full.data_ptr(), IW, IH, bind=False) if R.rank == 0 else None
+            self.carry = torch.zeros((IH, IW, 16), dtype=torch.float32, device=R.dev) if passes > 1 else None
+        self.my_pixels = self.r.shader.covered_pixels(dw, dh)
+        if R.sharded:
+            assert self.r.shader.owned_tiles(dw, dh)[0] <= self.tiles_per_rank
+        self.trace_events, self.gather_events, self.assemble_events = [], [], []
+
+    def step(self, timed, fresh):
+        """One frame.  fresh: the scheduler's cost history is dropped first (a frame it has not seen)."""
+        R, torch, r = self.R, self.R.torch, self.r
+        ev = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
+        with torch.cuda.stream(R.stream):
+            if fresh:
+                r.ctx.forget_costs()
+            e0, e1 = ev(), ev()
+            e0.record(R.stream)
+            if self.carry is None:
+                r.shader.dispatch_compute(self.dw, self.dh, 1)
+            else:
+                self.full.zero_(); self.carry.zero_()
+                for k in range(self.passes):
+                    r.shader.dispatch_accumulate(self.dw, self.dh, 1, k * self.spp, self.spp, self.carry.data_ptr())
+                r.shader.dispatch_resolve(self.dw, self.dh, 1, self.spp * self.passes)
+            e1.record(R.stream)
+            if timed:
+                self.trace_events.append((e0, e1))
+            if R.sharded:
+                e2 = ev()
+                if R.backend == "nccl":
+                    glist = list(self.gathered.unbind(0)) if R.rank == 0 else None
+                    R.dist.gather(self.tile_buf, glist, dst=0)
+                else:                                        # rehearsal path: gloo gathers host tensors
+                    R.stream.synchronize()
+                    host_buf = self.tile_buf.cpu()
+                    hlist = [torch.empty_like(host_buf) for _ in range(R.world)] if R.rank == 0 else None
+                    R.dist.gather(host_buf, hlist, dst=0)
+                    if R.rank == 0:
+                        self.gathered.copy_(torch.stack(hlist))
+                e2.record(R.stream)
+                if R.rank == 0:
+                    e3 = ev()
+                    r.shader.assemble_tiles(self.gathered.data_ptr(), R.world, self.tiles_per_rank, self.full_tex, self.dw, self.dh)
+                    e3.record(R.stream)
+                    if timed:
+                        self.assemble_events.append((e2, e3))
+                if timed:
+                    self.gather_events.append((e1, e2))
+
+    def run(self, steps, warmup, fresh):
+        """(seconds per step, max over ranks; total written pixels over ranks)"""
+        R = self.R
+        self.trace_events, self.gather_events, self.assemble_events = [], [], []
+        for _ in range(warmup):
+            self.step(False, fresh)
+        R.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step(True, fresh)
+        R.fence()
+        dt = time.perf_counter() - t0
+        dt = R.reduce([dt], "max")[0]
+        total_pixels = R.reduce([float(self.my_pixels)], "sum")[0]
+        return dt / steps, total_pixels
+
+    @staticmethod
+    def mean_ms(pairs):
+        return sum(a.elapsed_time(b) for a, b in pairs) / max(1, len(pairs))
+
+    def close(self):
+        self.r.close()
+
+
+def main():
+    args = parse_args()
+    if args.single_process_leg:
+        return single_process_leg(args)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
+
+    if args.rendezvous_only:
+        return rendezvous_only()
 
     # the contract is ONE JSON line on stdout: libraries that chat on fd 1 (RCCL prints a host / library banner when a
     # communicator is created) are sent to stderr for the duration of the run
@@ -56,168 +397,101 @@ def main():
     os.dup2(2, 1)
 
     import numpy as np
-    import torch
-    import torch.distributed as dist
-    from tdt4230_project_raytracing_amd import host, rt
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-        args.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the trace has no CPU path")
-    if args.backend == "gloo":
-        local_rank %= torch.cuda.device_count()              # rehearsal: ranks may share a device
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    sharded = world > 1 or args.force_dist
-    if sharded:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-
-    W, H, spp, bounce, desc = WORKLOADS[args.config]
-    if args.spp:
-        spp = args.spp
-    rows_factor = world if (world > 1 and args.scaling == "weak") else 1
-    scene = host.Scene.config(args.config)
-    cam = host.camera_reference_pose(W, H, spp, bounce)
-    if rows_factor > 1:
-        # same frustum, rows_factor x the pixel rows: every rank keeps one N=1 frame's worth of work
-        cam.image_height = H * rows_factor
-    IW, IH = cam.image_width, cam.image_height
-    dw, dh = IW + 1, IH + 1                      # main.rs:579
-
-    stream = torch.cuda.Stream(device=dev)
-    with torch.cuda.stream(stream):
-        full = torch.zeros((IH, IW, 4), dtype=torch.float32, device=dev) if rank == 0 else None
-        if not sharded:
-            r = rt.Renderer(scene, cam, device=local_rank, stream=stream.cuda_stream, image_ptr=full.data_ptr())
-            tiles_per_rank = 0
-            tile_buf = gathered = full_tex = None
-        else:
-            cover_w = min(max(dw // 32, 1) * 32, IW)
-            cover_h = min(max(dh // 32, 1) * 32, IH)
-            total_tiles = -(-cover_w // 32) * -(-cover_h // 32)
-            tiles_per_rank = -(-total_tiles // world)                # what rank 0 owns: the most
-            tile_buf = torch.zeros((tiles_per_rank, 32, 32, 4), dtype=torch.float32, device=dev)
-            r = rt.Renderer(scene, cam, device=local_rank, stream=stream.cuda_stream, rank=rank, world=world,
-                            image_ptr=tile_buf.data_ptr(), tile_buffer_tiles=tiles_per_rank)
-            gathered = torch.zeros((world, tiles_per_rank, 32, 32, 4), dtype=torch.float32, device=dev) if rank == 0 else None
-            full_tex = rt.Texture.wrap_device(r.ctx, full.data_ptr(), IW, IH, bind=False) if rank == 0 else None
-    carry = None
+    R = Rank(args)
+    world, rank = R.world, R.rank
+    args.gpus = world
+    scaling = "strong" if args.config == 4 else (args.scaling or "weak")
+    rows_factor = world if (world > 1 and scaling == "weak") else 1
+    if args.passes > 1 and R.sharded:
+        raise SystemExit("--passes is a single-GPU option")
     if args.passes > 1:
-        if sharded:
-            raise SystemExit("--passes is a single-GPU option")
-        with torch.cuda.stream(stream):
-            carry = torch.zeros((IH, IW, 16), dtype=torch.float32, device=dev)
         args.no_cpu_baseline = True
-    my_pixels = r.shader.covered_pixels(dw, dh)
-    if sharded:
-        assert r.shader.owned_tiles(dw, dh)[0] <= tiles_per_rank
 
-    ev_pairs = []
+    wl = Workload(R, args.config, spp=args.spp, rows_factor=rows_factor, passes=args.passes)
+    spp, IW, IH, dw, dh, r, scene, cam = wl.spp, wl.IW, wl.IH, wl.dw, wl.dh, wl.r, wl.scene, wl.cam
+    progressive = args.passes > 1
 
-    first_pair = []
+    # the context's very first dispatch (includes the one-time LDS-table build and scan): reported, not the headline
+    torch = R.torch
+    with torch.cuda.stream(R.stream):
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f0.record(R.stream)
+        if not progressive:
+            r.shader.dispatch_compute(dw, dh, 1)
+        f1.record(R.stream)
+    R.fence()
+    first_dispatch_ms = f0.elapsed_time(f1) if not progressive else None
 
-    def step(timed):
-        with torch.cuda.stream(stream):
-            if not timed and not first_pair:             # the context's very first dispatch: image order, no cost history
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-                first_pair.extend([e0, e1])
-                timed_first = True
-            else:
-                timed_first = False
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-            if carry is None:
-                r.shader.dispatch_compute(dw, dh, 1)
-            else:
-                full.zero_(); carry.zero_()
-                r.shader.dispatch_accumulate(dw, dh, 1, 0, spp, carry.data_ptr())
-            if timed:
-                e1.record(stream)
-                ev_pairs.append((e0, e1))
-            if timed_first:
-                first_pair[1].record(stream)
-            if carry is not None:
-                for k in range(1, args.passes):
-                    r.shader.dispatch_accumulate(dw, dh, 1, k * spp, spp, carry.data_ptr())
-                r.shader.dispatch_resolve(dw, dh, 1, spp * args.passes)
-            if sharded:
-                if args.backend == "nccl":
-                    glist = list(gathered.unbind(0)) if rank == 0 else None
-                    dist.gather(tile_buf, glist, dst=0)
-                else:                                        # rehearsal path: gloo gathers host tensors
-                    stream.synchronize()
-                    host_buf = tile_buf.cpu()
-                    hlist = [torch.empty_like(host_buf) for _ in range(world)] if rank == 0 else None
-                    dist.gather(host_buf, hlist, dst=0)
-                    if rank == 0:
-                        gathered.copy_(torch.stack(hlist))
-                if rank == 0:
-                    r.shader.assemble_tiles(gathered.data_ptr(), world, tiles_per_rank, full_tex, dw, dh)
-
-    def fence():
-        if sharded:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        step(False)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    fence()
-    dt = time.perf_counter() - t0
-    tt = torch.tensor([dt, float(my_pixels)], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-    if sharded:
-        tmax = tt.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = tt.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt, total_pixels = float(tmax[0]), float(tsum[1])
-    else:
-        total_pixels = float(my_pixels)
-    ms_per_step = dt / args.steps * 1e3
+    # ---- the headline: frames the scheduler has not seen (unless --replay) ---------------------------------------------
+    fresh = not args.replay and not progressive
+    sec, total_pixels = wl.run(args.steps, args.warmup, fresh)
+    ms_per_step = sec * 1e3
     samples_per_step = total_pixels * spp * args.passes
-    value = samples_per_step / (dt / args.steps) / 1e6
+    value = samples_per_step / sec / 1e6
+    frame_kernel_ms = Workload.mean_ms(wl.trace_events)
+    gather_ms = Workload.mean_ms(wl.gather_events) if R.sharded else None
+    assemble_ms = Workload.mean_ms(wl.assemble_events) if (R.sharded and rank == 0) else None
+    rank_trace_ms = R.gather_floats(frame_kernel_ms)
 
-    # --- roofline of the dominant kernel (the trace kernel), measured on rank 0 -----------------
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(1, len(ev_pairs))
-    counts = r.shader.dispatch_counted(dw, dh, 1)          # instrumented, untimed: algorithmic events of ONE launch
-    # 8 B per Node load + material / albedo / attribute reads + 40 B of octree uniforms
-    read_bytes = (8 * counts["node_loads"] + 24 * counts["lambertian"] + 28 * counts["metal"]
-                  + 16 * counts["dielectric"] + 40)
-    write_bytes = 16 * counts["pixels"]
-    achieved = read_bytes / (kernel_ms * 1e-3) / 1e9
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tfile):
-        try:
-            tj = json.load(open(tfile))
-            key = f"config{args.config}_spp{spp}_gpus{world}"
-            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "kernel": "tdt::trace_kernel<false,...> (COUNT = false: the product build)", "kernel_ms": round(kernel_ms, 4),
-                "algorithmic_read_bytes": int(read_bytes), "algorithmic_write_bytes": int(write_bytes),
-                "node_loads": counts["node_loads"], "rays": counts["octree_hit_calls"]}
+    # phases of a history-free frame (probe / main / resolve) from events recorded inside the library, a few more frames
+    phase = None
+    if fresh and rank == 0 and not R.sharded:
+        r.ctx.phase_timing(True)
+        acc = np.zeros(3)
+        for _ in range(5):
+            wl.step(False, True)
+            acc += np.array(r.ctx.phase_timing(True))
+        phase = [float(v) for v in acc / 5]
+        r.ctx.phase_timing(False)
 
-    # --- CPU baseline: the oracle (a port, not the product) on a bounded sample ----------------
+    # ---- the other schedule, for the record -----------------------------------------------------------------------------
+    other_ms = None
+    if not progressive:
+        wl.step(False, False)                                # (a replay needs a recorded frame)
+        other_sec, _ = wl.run(args.steps, 1, not fresh)
+        other_ms = other_sec * 1e3
+
+    # ---- roofline of the dominant kernel: the main launch of the frame, measured on rank 0 ------------------------------
+    roofline = None
+    if rank == 0:
+        counts_frame = r.shader.dispatch_counted(dw, dh, 1)        # instrumented, untimed: algorithmic events of the whole frame
+        read_bytes, write_bytes = algorithmic_bytes(counts_frame)
+        kernel_ms, kernel_note, main_read = frame_kernel_ms, "whole dispatch (one launch)", read_bytes
+        if phase is not None and phase[0] > 0:
+            # a two-phase frame: the dominant launch is the main one (samples [spp/16, spp)); count ITS algorithmic events
+            probe = spp // 16
+            with torch.cuda.stream(R.stream):
+                c = torch.zeros((IH, IW, 16), dtype=torch.float32, device=R.dev)
+                wl.full.zero_()
+            R.stream.synchronize()
+            r.shader.dispatch_accumulate(dw, dh, 1, 0, probe, c.data_ptr())
+            counts_main = r.shader.dispatch_counted_range(dw, dh, 1, probe, spp - probe, c.data_ptr())
+            main_read, _ = algorithmic_bytes(counts_main)
+            kernel_ms, kernel_note = phase[1], f"main launch of the two-phase frame: samples [{probe}, {spp}) of every pixel in the cost order of this frame's probe"
+            del c
+        achieved = main_read / (kernel_ms * 1e-3) / 1e9
+        wkey = f"config{args.config}_spp{spp}_gpus{world}"
+        traffic = (quoted("traffic.json", wkey) or {}).get("hbm_bytes_per_launch")
+        valu = quoted("r02_pmc_summary.json", wkey)
+        roofline = {"bound": "hbm", "bound_note": "NOMINAL: algorithmic bytes (what a cache-less implementation would fetch: 8 B per tree level visited, SURVEY §8d) "
+                             "over the HBM peak.  The tree is served from LDS / L2, so measured HBM traffic is far below the algorithmic bytes and the "
+                             "kernel is physically bound by VALU issue and lane divergence: see `valu`",
+                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                    "traffic": traffic, "traffic_note": "measured HBM bytes per frame (rocprofv3 TCC counters, profiles/traffic.json): << algorithmic",
+                    "kernel": "tdt::trace_kernel<false, ...> (COUNT = false: the product build)", "kernel_launch": kernel_note,
+                    "kernel_ms": round(kernel_ms, 4), "algorithmic_read_bytes": int(main_read),
+                    "frame": {"dispatch_ms": round(frame_kernel_ms, 4), "algorithmic_read_bytes": int(read_bytes), "algorithmic_write_bytes": int(write_bytes),
+                              "node_loads": counts_frame["node_loads"], "rays": counts_frame["octree_hit_calls"],
+                              "frac_of_hbm_peak": round(read_bytes / (frame_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                    "phases_ms": {"probe": round(phase[0], 4), "main": round(phase[1], 4), "resolve": round(phase[2], 4)} if phase else None,
+                    "valu": valu}
+
+    # ---- CPU baseline: the oracle (a port, not the product) on a bounded sample; the reference's own llvmpipe figure quoted ----
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        r.ctx.forget_costs()
+        r.shader.dispatch_compute(dw, dh, 1)
+        R.stream.synchronize()
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_py
         orc = oracle_py.Oracle()
@@ -234,41 +508,74 @@ def main():
         cpu_baseline = {"value": round(px * spp / tc / 1e6, 3), "unit": "Mray-samples/s", "cores": cores, "kind": "port",
                         "sample": f"{bands} bands of {band_rows} rows ({px} px x {spp} spp) of the same frame, {tc:.1f} s"}
         # spot-check the product against the checker on the sampled rows (never the other way round)
-        got = full.cpu().numpy()
+        got = wl.full.cpu().numpy()
         bad = 0
         for y0 in ys:
             bad += int((got[y0:y0 + band_rows].view(np.uint32) != img[y0:y0 + band_rows].view(np.uint32)).any(axis=2).sum())
         cpu_baseline["mismatched_pixels_in_sample"] = bad
+        cpu_baseline["reference_llvmpipe"] = quoted("llvmpipe_baseline.json", f"config{args.config}_spp{spp}")
+    wl.close()
 
-    if rank == 0:
-        out = {
-            "metric": "Mray-samples/sec at 1080p/64spp/depth-8" if args.config == 2 and spp == 64 and args.passes == 1 else f"Mray-samples/sec (config {args.config}, {spp * args.passes} spp" + (f" as {args.passes} progressive passes" if args.passes > 1 else "") + ")",
-            "value": round(value, 2), "unit": "Mray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": args.scaling if world > 1 else "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc + (f"; x{rows_factor} pixel rows over the same frustum (weak scaling)" if rows_factor > 1 else ""),
-                       "image": [IW, IH], "dispatch": [dw, dh, 1], "written_pixels": int(total_pixels), "spp": spp * args.passes,
-                       "passes": args.passes,
-                       "max_bounce": bounce, "octree_max_depth": scene.max_depth, "octree_cells": scene.counts["cells"],
-                       "scene_bytes": scene.nbytes(),
-                       "schedule": "global pixel queue; pixels handed out most-expensive-first from the work counts (tree levels, "
-                                   "steps, path events) the previous dispatch recorded per pixel (a bench step repeats the same frame; "
-                                   "when the camera or scene changed, 8x8 tiles are ordered instead); the first dispatch of a "
-                                   "context runs in image order (TDT_NO_COST_ORDER=1: always) — first_dispatch_ms is that dispatch, timed "
-                                   "during warm-up",
-                       "first_dispatch_ms": round(first_pair[0].elapsed_time(first_pair[1]), 4) if first_pair else None,
-                       "partition": f"32x32 work-groups dealt round-robin over {world} rank(s)" + ("; one RCCL gather + de-interleave per step" if sharded else "")},
-            "roofline": roofline,
-            "cpu_baseline": cpu_baseline,
-        }
-        sys.stdout.flush()
-        os.dup2(real_stdout, 1)
-        print(json.dumps(out), flush=True)
-        os.dup2(2, 1)
-    r.close()
-    if sharded:
-        dist.destroy_process_group()
+    # ---- BASELINE configs[3]: ONE 8K frame, strong-sharded over the ranks -------------------------------------------------
+    strong = None
+    if not args.no_strong and args.config != 4 and not progressive:
+        sw = Workload(R, 4, rows_factor=1)
+        ssec, spx = sw.run(args.strong_steps, 1, True)
+        strace = R.gather_floats(Workload.mean_ms(sw.trace_events))
+        strong = {"workload": WORKLOADS[4][4], "image": [sw.IW, sw.IH], "spp": sw.spp, "written_pixels": int(spx),
+                  "steps": args.strong_steps, "ms_per_frame": round(ssec * 1e3, 3), "value": round(spx * sw.spp / ssec / 1e6, 2),
+                  "unit": "Mray-samples/s", "scaling": "strong", "trace_ms_per_rank": [round(v, 3) for v in strace],
+                  "gather_ms": round(Workload.mean_ms(sw.gather_events), 3) if R.sharded else 0.0,
+                  "gather_note": "from the end of rank 0's trace to the end of the gather on rank 0: includes waiting for the slowest rank",
+                  "assemble_ms": round(Workload.mean_ms(sw.assemble_events), 3) if (R.sharded and rank == 0) else 0.0,
+                  "tile_buffer_bytes_per_rank": int(sw.tiles_per_rank) * 32 * 32 * 16,
+                  "schedule": "every frame history-free (tdt_forget_costs): two-phase on each rank"}
+        sw.close()
+
+    R.fence()
+    R.close()
+    if rank != 0:
+        return
+
+    # ---- the same 8K frame through the C ABI's multi-device context, one process (a fresh one) ------------------------------
+    single = None
+    if not args.no_single_process and not progressive:
+        torch.cuda.synchronize()
+        single = run_single_process_child(args, world)
+
+    desc = wl.desc
+    out = {
+        "metric": "Mray-samples/sec at 1080p/64spp/depth-8" if args.config == 2 and spp == 64 and args.passes == 1 else f"Mray-samples/sec (config {args.config}, {spp * args.passes} spp" + (f" as {args.passes} progressive passes" if args.passes > 1 else "") + ")",
+        "value": round(value, 2), "unit": "Mray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": scaling if world > 1 else "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": desc + (f"; x{rows_factor} pixel rows over the same frustum (weak scaling)" if rows_factor > 1 else ""),
+                   "image": [IW, IH], "dispatch": [dw, dh, 1], "written_pixels": int(total_pixels), "spp": spp * args.passes,
+                   "passes": args.passes,
+                   "max_bounce": wl.bounce, "octree_max_depth": scene.max_depth, "octree_cells": scene.counts["cells"],
+                   "scene_bytes": scene.nbytes(),
+                   "schedule": ("every timed step is a frame the scheduler has not seen (tdt_forget_costs before it): spp/16 probe samples per pixel in "
+                                "image order, then the rest most-expensive-pixel-first from the probe's work counts, then the resolve"
+                                if fresh else "replay: every timed step repeats the frame before it, pixels handed out most-expensive-first from "
+                                "the work counts that frame recorded") if not progressive else "progressive passes (running sums + carry through HBM)",
+                   "replay_ms": round(other_ms if fresh else ms_per_step, 4) if other_ms is not None else None,
+                   "history_free_ms": round(ms_per_step if fresh else other_ms, 4) if other_ms is not None else None,
+                   "first_dispatch_ms": round(first_dispatch_ms, 4) if first_dispatch_ms is not None else None,
+                   "first_dispatch_note": "the context's very first frame: includes the one-time LDS-table build and scan of the cells buffer",
+                   "trace_ms_per_rank": [round(v, 4) for v in rank_trace_ms],
+                   "gather_ms": round(gather_ms, 4) if gather_ms is not None else None,
+                   "assemble_ms": round(assemble_ms, 4) if assemble_ms is not None else None,
+                   "partition": f"32x32 work-groups dealt round-robin over {world} rank(s)" + ("; one RCCL gather + de-interleave per step" if R.sharded else "")},
+        "roofline": roofline,
+        "cpu_baseline": cpu_baseline,
+        "strong": strong,
+        "single_process": single,
+    }
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    print(json.dumps(out), flush=True)
+    os.dup2(2, 1)
 
 
 if __name__ == "__main__":

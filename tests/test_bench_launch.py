@@ -1,0 +1,74 @@
+"""bench.py's launch path: `python bench.py --gpus N` outside torchrun must start its N ranks itself (the shape of the
+driver's N=1 command with N>1), give them torchrun's environment, and pass ONE JSON line through.  CPU: the ranks only
+rendezvous (gloo); GPU: the real thing with two ranks sharing the one device."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_rank_environments_look_like_torchrun():
+    envs = bench.rank_environments(3, 29999, base={"PATH": "/bin"})
+    assert [e["RANK"] for e in envs] == ["0", "1", "2"] and [e["LOCAL_RANK"] for e in envs] == ["0", "1", "2"]
+    assert all(e["WORLD_SIZE"] == "3" and e["MASTER_ADDR"] == "127.0.0.1" and e["MASTER_PORT"] == "29999" for e in envs)
+    assert all(e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and e["PATH"] == "/bin" for e in envs)
+
+
+def test_arguments_and_workloads():
+    a = bench.parse_args(["--gpus", "8", "--steps", "20", "--warmup", "5"])
+    assert (a.gpus, a.steps, a.warmup, a.config) == (8, 20, 5, 2)
+    assert bench.parse_args([]).gpus == 1
+    W, H, spp, bounce, desc, scene_cfg = bench.WORKLOADS[4]                     # BASELINE configs[3]
+    assert (W, H, spp, bounce) == (7680, 4320, 64, 8) and "256^3" in desc
+    assert bench.WORKLOADS[2][:4] == (1920, 1080, 64, 8)                       # the metric's configuration
+    r, w = bench.algorithmic_bytes({"node_loads": 10, "lambertian": 2, "metal": 1, "dielectric": 1, "pixels": 4})
+    assert r == 80 + 48 + 28 + 16 + 40 and w == 64
+
+
+def test_self_launch_spawns_ranks_that_meet():
+    """The driver's shape of command: no torchrun, --gpus 3 — three child processes rendezvous over gloo on 127.0.0.1."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--rendezvous-only"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    assert json.loads(lines[0]) == {"rendezvous": 3, "rank_sum": 3.0, "ranks_seen": 3}
+
+
+def test_a_failing_rank_fails_the_launch():
+    """Without a GPU the ranks exit with an error: the launcher must report that, not hang and not print a line."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert "needs a GPU" in p.stderr
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_self_launched_on_one_gpu():
+    """`python bench.py --gpus 2 --backend gloo --steps 1 --warmup 1` as a fresh child: rc 0 and one JSON line that carries the
+    weak-scaled headline, the strong 8K block with its per-rank times, and the single-process (multi-device context) block."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "1",
+                        "--strong-steps", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0 and j["config"]["image"] == [1920, 2160]
+    assert len(j["config"]["trace_ms_per_rank"]) == 2 and j["config"]["gather_ms"] is not None
+    s = j["strong"]
+    assert s["image"] == [7680, 4320] and s["spp"] == 64 and s["written_pixels"] == 7680 * 4320 and len(s["trace_ms_per_rank"]) == 2
+    sp = j["single_process"]
+    assert "error" not in sp, sp
+    assert sp["devices"] == [0, 0] and sp["written_pixels"] == 7680 * 4320 and sp["transport"] == "copy"

@@ -1,7 +1,9 @@
-"""BASELINE.json's configurations at FULL image size.  The oracle needs minutes for a whole frame, so
-whole-frame checks use size-independent properties (determinism, invariance under the work
-partition / the progressive split / the kernel specialisation, sample-count linearity of the running
-sums) on a checksum of the frame, and the oracle checks bands of rows sampled across the frame."""
+"""BASELINE.json's configurations at their STATED size and sampling: configs[1] 1080p / 16 spp / bounce 8, configs[2] 4K /
+64 spp / bounce 16, configs[3] the 8K / 64 spp frame of the 8-GPU config (here on one GPU: eight ranks' shares one after the
+other, and eight shares of one multi-device context), configs[4] 1080p / 1024 spp as 16 progressive passes of 64.  The oracle
+needs minutes for a whole frame, so whole-frame checks use size-independent properties (determinism, invariance under the
+work partition / the progressive split / the kernel specialisation / the schedule) on a checksum of the frame, and the oracle
+checks narrow bands of rows sampled across the frame."""
 import hashlib
 
 import numpy as np
@@ -11,9 +13,8 @@ from tdt4230_project_raytracing_amd import host, rt, tiles
 
 pytestmark = pytest.mark.gpu
 
-# config -> (W, H, spp, max_bounce): configs[1] as stated; configs[2] / [3] (the 8K frame of the 8-GPU config, here on
-# one GPU) / [4] at reduced spp (time)
-FULL = {2: (1920, 1080, 16, 8), 3: (3840, 2160, 4, 16), 4: (7680, 4320, 2, 8), 5: (1920, 1080, 8, 8)}
+# config -> (W, H, spp, max_bounce, progressive passes, oracle bands, rows per band): all as BASELINE.json states them
+FULL = {2: (1920, 1080, 16, 8, 1, 6, 4), 3: (3840, 2160, 64, 16, 1, 4, 4), 4: (7680, 4320, 64, 8, 1, 3, 4), 5: (1920, 1080, 1024, 8, 16, 3, 2)}
 
 
 def digest(img):
@@ -22,12 +23,24 @@ def digest(img):
 
 @pytest.fixture(scope="module", params=sorted(FULL))
 def frame(request):
+    import torch
     cfg = request.param
-    W, H, spp, bounce = FULL[cfg]
+    W, H, spp, bounce, passes, _, _ = FULL[cfg]
     scene = host.Scene.config(cfg)
     cam = host.camera_reference_pose(W, H, spp, bounce)
     r = rt.Renderer(scene, cam)
-    img = r.render()
+    if passes == 1:
+        img = r.render()
+    else:
+        # configs[4] as specified: `passes` progressive passes through tdt_dispatch_accumulate (running sums + the shader's
+        # loop-carried temporaries through HBM), ONE resolve
+        per = spp // passes
+        carry = torch.zeros((H, W, 16), dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        for k in range(passes):
+            r.shader.dispatch_accumulate(W + 1, H + 1, 1, k * per, per, carry.data_ptr())
+        r.shader.dispatch_resolve(W + 1, H + 1, 1, spp)
+        img = r.texture.read()
     r.close()
     return cfg, scene, cam, img
 
@@ -43,12 +56,13 @@ def test_coverage_and_range(frame):
 def test_oracle_on_sampled_bands(oracle, frame):
     cfg, scene, cam, img = frame
     H = cam.image_height
-    ref = np.zeros_like(img)
-    rows = [int(i * (H - 40) / 6) // 8 * 8 for i in range(6)]
+    _, _, _, _, _, bands, nrows = FULL[cfg]
+    rows = [int((i + 0.5) * (H - 40) / bands) // 8 * 8 for i in range(bands)]
     for y0 in rows:
-        oracle.render(scene, cam, rows=(y0, y0 + 4), threads=16, image=ref)
-        eq = (img[y0:y0 + 4].view(np.uint32) == ref[y0:y0 + 4].view(np.uint32)).all(axis=2)
-        assert eq.all(), f"config {cfg}: rows {y0}..{y0 + 3}: {int((~eq).sum())} pixels differ from the oracle"
+        ref = np.zeros((y0 + nrows, cam.image_width, 4), np.float32)          # (the oracle only touches the rows it renders)
+        oracle.render(scene, cam, rows=(y0, y0 + nrows), threads=16, image=ref)
+        eq = (img[y0:y0 + nrows].view(np.uint32) == ref[y0:y0 + nrows].view(np.uint32)).all(axis=2)
+        assert eq.all(), f"config {cfg}: rows {y0}..{y0 + nrows - 1}: {int((~eq).sum())} pixels differ from the oracle"
 
 
 def test_deterministic_and_specialisation_invariant(frame, monkeypatch):
@@ -59,6 +73,10 @@ def test_deterministic_and_specialisation_invariant(frame, monkeypatch):
     sorted2 = r.render()
     r.close()
     assert digest(again) == digest(img) and digest(sorted1) == digest(img) and digest(sorted2) == digest(img)
+    r = rt.Renderer(scene, cam)
+    r.dispatch(); r.ctx.forget_costs()                 # a frame the scheduler "has not seen" although the context is warm
+    assert digest(r.render()) == digest(img)
+    r.close()
     monkeypatch.setenv("TDT_NO_SPECIALISE", "1")
     r = rt.Renderer(scene, cam)
     plain = r.render()
@@ -67,18 +85,32 @@ def test_deterministic_and_specialisation_invariant(frame, monkeypatch):
 
 
 def test_partition_invariant(frame):
-    """Three ranks' work-groups written into one full-size image = the single-rank frame."""
+    """The ranks' work-groups written into one full-size image = the single-rank frame (8 ranks for the 8-GPU config)."""
     import torch
     cfg, scene, cam, img = frame
     W, H = cam.image_width, cam.image_height
+    world = 8 if cfg == 4 else 3
     full = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
     torch.cuda.synchronize()          # torch filled it on ITS stream; the contexts below launch on their own
-    for rank in range(3):
-        r = rt.Renderer(scene, cam, rank=rank, world=3, image_ptr=full.data_ptr())
+    for rank in range(world):
+        r = rt.Renderer(scene, cam, rank=rank, world=world, image_ptr=full.data_ptr())
         r.dispatch()
         r.ctx.finish()
         r.close()
     assert digest(full.cpu().numpy()) == digest(img)
+
+
+def test_multi_device_context_invariant(frame):
+    """One multi-device context (tdt_ctx_create_multi): per-share tile buffers, one gather, de-interleave — the same frame.
+    configs[3] is the 8-GPU configuration: eight shares (on this one GPU)."""
+    cfg, scene, cam, img = frame
+    shares = 8 if cfg == 4 else 2
+    r = rt.Renderer(scene, cam, devices=[0] * shares)
+    got = r.render()
+    trace_ms, gather_ms, assemble_ms = r.ctx.multi_timing()
+    r.close()
+    assert digest(got) == digest(img)
+    assert len(trace_ms) == shares
 
 
 def test_progressive_invariant_and_linear(frame):
