@@ -32,7 +32,9 @@ def written_node(cells, p, depth):
         index = (((2 * value + ((q[0] >> sh) & 1)) << 1) + ((q[1] >> sh) & 1) << 1) + ((q[2] >> sh) & 1)
         if cells[2 * index + 1] == 0:
             return index
-        value = int(cells[2 * index])
+        if cells[2 * index + 1] == 2 and level < depth - 1:
+            return None                                  # a LEAF above the last level: the shader follows its material index as
+        value = int(cells[2 * index])                    # if it were a cell index, into the top of the tree — a real collision
     return index
 
 
@@ -47,7 +49,7 @@ def distinct_deltas(rng, n, depth, cells=None):
         seen, keep = set(), []
         for i, q in enumerate(pos):
             w = written_node(cells, q, depth)
-            if w not in seen:
+            if w is not None and w not in seen:
                 seen.add(w); keep.append(i)
                 if len(keep) == n:
                     break
