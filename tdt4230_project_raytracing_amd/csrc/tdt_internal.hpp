@@ -56,6 +56,8 @@ struct tdt_ctx {
   unsigned long long packed_version;
   uint32_t *slot_cost, *slot_acc, *slot_order, *order_hist;   // per queue slot: cost feedback of the last trace dispatch, the hand-out order derived from it; 2 x 256 sort counters
   uint32_t cost_dispatches;            // dispatches summed into slot_cost so far
+  uint32_t acc_samples, last_launch_samples;   // samples per pixel behind slot_acc / traced by the last launch
+  float order_blend;                   // TDT_ORDER_BLEND: weight of the 8x8-tile mean in a thin (probe) cost estimate
   uint32_t tile_capacity, cost_tiles;  // allocation size (work-groups); number of work-groups slot_cost holds the last dispatch's costs for (0: none)
   CostSig cost_sig;                    // what those costs were measured on (camera, octree parameters, buffer versions, partition)
   bool no_cost_order;           // TDT_NO_COST_ORDER=1: always hand work-groups out in image order

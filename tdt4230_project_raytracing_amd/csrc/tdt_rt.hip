@@ -149,8 +149,13 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       const float lx = (wx + -P.min_x) * P.inv_scale, ly = (wy + -P.min_y) * P.inv_scale, lz = (wz + -P.min_z) * P.inv_scale;
       bool in_box;
       if (POW2) {
-        // rc:417 "fract(p) - p != vec3(0)": fract(p) - p is zero exactly for p in [0,1) (and -0)
-        in_box = (lx >= 0.0f) & (lx < 1.0f) & (ly >= 0.0f) & (ly < 1.0f) & (lz >= 0.0f) & (lz < 1.0f);
+        // rc:417 "fract(p) - p != vec3(0)": fract(p) - p is zero exactly for p in [0,1) (and -0).  As ONE unsigned compare:
+        // the bit pattern of a float in [+0, 1) is below that of 1.0f; negative numbers carry the sign bit, NaN / inf / p >= 1
+        // are larger; and p + 0.0f is p for every p except -0, which it turns into +0 (so -0 passes, as it does in the shader).
+        // 3 adds + v_max3_u32 + 1 compare instead of 6 compares and 6 mask ANDs.
+        const uint32_t ux = __float_as_uint(lx + 0.0f), uy = __float_as_uint(ly + 0.0f), uz = __float_as_uint(lz + 0.0f);
+        const uint32_t um = ux > uy ? ux : uy;
+        in_box = (um > uz ? um : uz) < 0x3F800000u;
       } else {
         const float ex = f_fract(lx) + -lx, ey = f_fract(ly) + -ly, ez = f_fract(lz) + -lz;
         in_box = !((__builtin_fabsf(ez) + __builtin_fabsf(ey)) != -__builtin_fabsf(ex));
@@ -511,7 +516,16 @@ __device__ __forceinline__ uint32_t run_cost(uint32_t c) {          // wave-wide
   for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
   return t > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t;
 }
-__global__ __launch_bounds__(1024) void order_hist_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ acc, uint32_t n, uint32_t *__restrict__ hist, uint32_t g, int smooth, int keep) {
+// blend > 0 (per-pixel order from a THIN history: the few probe samples of a two-phase frame): a pixel's estimate is shrunk
+// towards the mean of its 8x8 tile — neighbours see the same surfaces, so their 64 x more samples say more about what this
+// pixel's remaining samples will cost than its own few do.  What it buys is the END of the frame: a pixel whose probe samples
+// happened to be cheap no longer starts last and finishes alone (probe order: the last wave ended 8 % after the first).
+__device__ __forceinline__ uint32_t blended_cost(uint32_t a, float blend) {
+  const float tile_mean = (float)run_cost(a) * (1.0f / 64.0f);
+  const float v = (1.0f - blend) * (float)a + blend * tile_mean;
+  return a == 0u ? 0u : (uint32_t)(v < 1.0f ? 1.0f : (v > 4.0e9f ? 4.0e9f : v));     // (0 = never run: stays last)
+}
+__global__ __launch_bounds__(1024) void order_hist_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ acc, uint32_t n, uint32_t *__restrict__ hist, uint32_t g, int smooth, int keep, float blend) {
   __shared__ uint32_t s_bin[512];
   if (threadIdx.x < 512) s_bin[threadIdx.x] = 0;
   __syncthreads();
@@ -522,20 +536,20 @@ __global__ __launch_bounds__(1024) void order_hist_kernel(const uint32_t *__rest
     const uint32_t c = cost[i], before = keep ? acc[i] : 0u, a = before + c < before ? 0xFFFFFFFFu : before + c;
     acc[i] = a;
     if (smooth) { const uint32_t k = order_key(run_cost(a), g); if ((threadIdx.x & 63u) == 0) atomicAdd(&s_bin[k], 64u); }
-    else atomicAdd(&s_bin[order_key(a, g)], 1u);
+    else atomicAdd(&s_bin[order_key(blend > 0.0f ? blended_cost(a, blend) : a, g)], 1u);
   }
   __syncthreads();
   if (threadIdx.x < 512 && s_bin[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_bin[threadIdx.x]);
 }
 __global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restrict__ cost, uint32_t *__restrict__ acc, uint32_t n, const uint32_t *__restrict__ hist,
-                                                             uint32_t *__restrict__ cursor, uint32_t *__restrict__ order, uint32_t g, int smooth) {
+                                                             uint32_t *__restrict__ cursor, uint32_t *__restrict__ order, uint32_t g, int smooth, float blend) {
   __shared__ uint32_t s_bin[512], s_base[512];
   if (threadIdx.x < 512) s_bin[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t lo = blockIdx.x * kOrderChunk, hi = lo + kOrderChunk < n ? lo + kOrderChunk : n;
   for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) {
     if (smooth) { const uint32_t k = order_key(run_cost(acc[i]), g); if ((threadIdx.x & 63u) == 0) atomicAdd(&s_bin[k], 64u); }
-    else atomicAdd(&s_bin[order_key(acc[i], g)], 1u);
+    else atomicAdd(&s_bin[order_key(blend > 0.0f ? blended_cost(acc[i], blend) : acc[i], g)], 1u);
   }
   __syncthreads();
   if (threadIdx.x < 512) {
@@ -553,7 +567,7 @@ __global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restric
       pos = (uint32_t)__shfl((int)pos, 0, 64);
       order[pos + (threadIdx.x & 63u)] = i;
     } else {
-      order[atomicAdd(&s_base[order_key(acc[i], g)], 1u)] = i;
+      order[atomicAdd(&s_base[order_key(blend > 0.0f ? blended_cost(acc[i], blend) : acc[i], g)], 1u)] = i;
     }
     cost[i] = 0;
     // tile-sum mode = the inputs changed: these costs served once, as a prior for this dispatch's order; the estimate for
@@ -804,10 +818,15 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
         // estimate of what a pixel costs; otherwise start over
         const bool keep_costs = !smooth && !ctx->no_cost_accum && ctx->cost_dispatches < 256;   // (restart before the sums can saturate)
         ctx->cost_dispatches = keep_costs ? ctx->cost_dispatches + 1 : 0;
+        // samples per pixel behind the estimate this order is built from; a thin one (the probe of a two-phase frame) is
+        // shrunk towards the 8x8-tile mean (blended_cost)
+        ctx->acc_samples = (keep_costs ? ctx->acc_samples : 0u) + ctx->last_launch_samples;
+        const float blend = (!smooth && ctx->acc_samples < 16u) ? ctx->order_blend : 0.0f;
+        if (smooth) ctx->acc_samples = 0;               // (tile-sum mode drops the sums after use: order_scatter_kernel)
         const uint32_t n_slots = (uint32_t)t.owned * 1024u, n_chunks = (n_slots + tdt::kOrderChunk - 1) / tdt::kOrderChunk;
         const uint32_t og = tdt::kOrderBits;
         TDT_HIP(ctx, hipMemsetAsync(ctx->order_hist, 0, 1024 * sizeof(uint32_t), ctx->stream));
-        hipLaunchKernelGGL(tdt::order_hist_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, ctx->slot_acc, n_slots, ctx->order_hist, og, smooth, keep_costs ? 1 : 0);
+        hipLaunchKernelGGL(tdt::order_hist_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, ctx->slot_acc, n_slots, ctx->order_hist, og, smooth, keep_costs ? 1 : 0, blend);
         {
           const float max_share = ctx->max_share;
           const uint32_t lanes = (uint32_t)ctx->num_cus * TDT_BLOCKS_PER_CU * TDT_BLOCK;
@@ -816,14 +835,15 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
           P.plan = ctx->order_hist + 1024;
         }
         hipLaunchKernelGGL(tdt::order_scatter_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, ctx->slot_acc, n_slots,
-                           ctx->order_hist, ctx->order_hist + 512, ctx->slot_order, og, smooth);
+                           ctx->order_hist, ctx->order_hist + 512, ctx->slot_order, og, smooth, blend);
         TDT_HIP(ctx, hipGetLastError());
         P.slot_order = ctx->slot_order;
       } else {                                        // no usable history: image order, fresh cost array
         TDT_HIP(ctx, hipMemsetAsync(ctx->slot_cost, 0, (size_t)t.owned * 1024 * sizeof(uint32_t), ctx->stream));
         TDT_HIP(ctx, hipMemsetAsync(ctx->slot_acc, 0, (size_t)t.owned * 1024 * sizeof(uint32_t), ctx->stream));
-        ctx->cost_dispatches = 0;
+        ctx->cost_dispatches = 0; ctx->acc_samples = 0;
       }
+      ctx->last_launch_samples = (uint32_t)(spp_count > 0 ? spp_count : 0);
       ctx->cost_sig = sig;
       ctx->cost_tiles = (uint32_t)t.owned;            // the kernel launched below records this dispatch's costs
     }
@@ -918,7 +938,8 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
     const char *fs = getenv("TDT_ORDER_SMOOTH"); ctx->force_smooth = fs ? atoi(fs) : -1;
     ctx->no_cost_accum = getenv("TDT_NO_COST_ACCUM") != nullptr;
     ctx->no_two_phase = getenv("TDT_NO_TWO_PHASE") != nullptr;
-    const char *ms = getenv("TDT_MAX_SHARE"); ctx->max_share = ms ? (float)atof(ms) : 0.25f; }
+    const char *ms = getenv("TDT_MAX_SHARE"); ctx->max_share = ms ? (float)atof(ms) : 0.25f;
+    const char *ob = getenv("TDT_ORDER_BLEND"); ctx->order_blend = ob ? (float)atof(ob) : 0.5f; }
   ctx->scan = nullptr; ctx->max_parent_value = ctx->max_any_value = 0xFFFFFFFFu;
   { hipDeviceProp_t prop; ctx->num_cus = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
   { const char *fg = getenv("TDT_FORCE_GENERIC"); ctx->force_generic = fg && fg[0] == '1';
