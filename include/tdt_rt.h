@@ -188,11 +188,6 @@ int tdt_dispatch_counted_range(tdt_compute *c, int width, int height, int depth,
  * context (two-phase, probe in image order) whatever was traced before.  Only the schedule changes, never a pixel.
  * (Measurement: bench.py times frames "the scheduler has not seen" with it.) */
 int tdt_forget_costs(tdt_ctx *ctx);
-/* end-of-frame helping (csrc/tdt_rt.hip "Helping": lanes that find the pixel queue dry trace sample ranges of pixels other
- * lanes of their block still own; same bits, shorter tail; TDT_NO_HELP=1 in the environment switches it off): running totals
- * of the context — [0] ranges offered, [1] taken, [2] traced again by the owner because the helper read a hit record it had
- * not written, [3] pixels merged.  Synchronises. */
-int tdt_debug_help_stats(tdt_ctx *ctx, uint64_t out[4]);
 /* measurement aid: enable != 0 records HIP events around the launches of every following tdt_dispatch_compute; ms (may be
  * NULL) receives the times of the LAST frame: {probe launch, main launch (+ the sort that orders it), resolve} for a
  * two-phase frame, {0, the one launch, 0} otherwise.  Blocks until that frame has finished. */

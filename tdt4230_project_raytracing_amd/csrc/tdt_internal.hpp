@@ -70,8 +70,6 @@ struct tdt_ctx {
   float event_k;        // TDT_EVENT_K overrides the adaptive threshold's r (0: chosen from the tree size)
   void *frame_carry; size_t frame_carry_bytes;   // hit-record carry between the two phases of a frame (tdt_dispatch_compute)
   bool no_two_phase;                             // TDT_NO_TWO_PHASE=1
-  float help_share;              // TDT_HELP_SHARE: order_plan_kernel's threshold for the helping build (share of the frame a 99.9th-percentile pixel occupies its lane)
-  float *help_colour; uint32_t *help_seg; bool no_help;   // side buffers of the end-of-frame helping (trace_kernel); TDT_NO_HELP=1
   bool probe_launch;                             // set around the probe launch of a two-phase frame (kernel name only)
   bool phase_timing; hipEvent_t phase_ev[4]; int phase_n;   // tdt_debug_phase_timing: events around the launches of the last frame
   uint32_t *present; size_t present_bytes;   // staging of tdt_image_read_rgba8
@@ -132,7 +130,6 @@ int multi_dispatch_compute(tdt_compute *c, int width, int height, int depth);
 int multi_dispatch_counted(tdt_compute *c, int width, int height, int depth, uint64_t counts[8]);
 int multi_forget_costs(tdt_ctx *ctx);
 tdt_ctx *multi_first_member(tdt_ctx *front);
-tdt_ctx *multi_member(tdt_ctx *front, int i);
 
 // ---- tdt_edit.hip ----
 int launch_update(tdt_compute *c, int width, int height, int depth);

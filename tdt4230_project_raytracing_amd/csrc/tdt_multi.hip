@@ -342,7 +342,6 @@ int multi_dispatch_counted(tdt_compute *c, int width, int height, int depth, uin
 }
 
 tdt_ctx *multi_first_member(tdt_ctx *front) { return front->multi->member[0]; }
-tdt_ctx *multi_member(tdt_ctx *front, int i) { return front->multi->member[(size_t)i]; }
 
 int multi_forget_costs(tdt_ctx *front) {
   for (tdt_ctx *m : front->multi->member) (void)tdt_forget_costs(m);

@@ -54,10 +54,6 @@ TDT_DEV bool pixel_of_thread(const TraceParams &P, int &x, int &y, size_t &pix) 
   return inside;
 }
 
-TDT_DEV bool m_wait_or_new(int state, bool now_idle) {     // any lane of the wave idle, merging, or just out of work?
-  return __ballot(state == 7 /* ST_IDLE */ || state == 8 /* ST_MERGE */ || now_idle) != 0ull;
-}
-
 TDT_DEV uint32_t wave_sum(uint32_t v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
@@ -68,30 +64,7 @@ TDT_DEV uint32_t wave_sum(uint32_t v) {
 // is run per lane as a state machine, so lanes of one wave can be in different samples /
 // bounces / steps at the same time; every lane still executes exactly the reference's sequence
 // of operations for its own pixel, in the same order (bit-identical sums).
-enum : int { ST_TRAVERSE = 0, ST_HIT = 1, ST_END = 2, ST_FETCH = 3, ST_PRIMARY = 4, ST_NEWRAY = 5, ST_DONE = 6,
-             ST_IDLE = 7,     // helping: the global queue is dry; the lane looks for sample ranges other lanes of its block offer
-             ST_MERGE = 8 };  // helping: the owner of a pixel has finished its own samples and waits for the ranges it gave away
-
-// Helping — the end of a frame.  A lane owns a pixel for all of its samples, so once the global queue is dry a kernel lasts
-// as long as its unluckiest lane: in the order of a two-phase frame's probe the last wave ended 8 % after the first (64^3
-// scene), and where single samples can be very long (512^3 shells) a frame that is not a replay took 25 % longer than one
-// that is.  So lanes that find the queue dry stay and help the lanes of their own BLOCK (one CU, one LDS, one L1 — nothing
-// below needs more than work-group-scope ordering):
-//   offer   at a sample boundary the owner of a pixel with >= 8 samples to go, seeing more idle lanes than offers, cuts the
-//           TOP of its sample range into pieces and posts them in an LDS ring (pixel, [begin, end), which of its <= 7 pieces);
-//   help    an idle lane takes a piece and traces those samples exactly as the owner would have — same pixel, same sample
-//           indices — but it cannot know the running colour sum nor the hit records CubeHit's call sites carry from sample
-//           to sample (see Carry), so it stores every sample's colour (side buffer in HBM, L2-served) and starts from
-//           blank records, noting whether it ever READ one before writing it ("taint": only rays that miss the octree's
-//           root cube, or a leaf whose slab test fails, do);
-//   merge   the owner, done with its own (lowest) samples, waits until its pieces are back (an LDS count), then adds their
-//           colours in sample order — the same additions in the same order as if it had traced them — and takes over the
-//           records they wrote.  A tainted piece and everything after it is simply traced again by the owner, now with
-//           the right records.
-// The image is the same bits (tested against the oracle at every size; TDT_NO_HELP=1 switches it off); only the frame's
-// tail goes.  Lanes retire when nobody in the block is tracing and the ring is empty (read in that order: only a tracing
-// lane can post).
-
+enum : int { ST_TRAVERSE = 0, ST_HIT = 1, ST_END = 2, ST_FETCH = 3, ST_PRIMARY = 4, ST_NEWRAY = 5, ST_DONE = 6 };
 
 // P.accumulate == 0: the whole of main() rc:234-252; 1: only the sample loop, adding to running sums (a uniform run-time
 // flag, looked at once per pixel, so the scene-specialised variants serve progressive passes too).
@@ -99,15 +72,8 @@ enum : int { ST_TRAVERSE = 0, ST_HIT = 1, ST_END = 2, ST_FETCH = 3, ST_PRIMARY =
 // POW2: exact-comparison treeLookup (see tree_lookup_pow2) vs the literal float form.
 // PROBE changes nothing but the kernel's name: the short probe launch of a two-phase frame (tdt_dispatch_compute) then shows
 // up as its own row in profiler statistics instead of halving the average of the launches that do the work.
-// HELP: the build with the end-of-frame helping compiled in (two more live registers per lane and the protocol's code cost the
-// frame 6-9 % whether or not anybody helps, so it is a build of its own, launched beside the plain one: P.plan[1], written on
-// the device from the cost histogram, says which of the two does the work — the other returns at once).
-template <bool COUNT, bool POW2, int DEPTH = 0, bool RESIDENT = false, bool SAFEV = false, bool PROBE = false, bool HELP = false>
+template <bool COUNT, bool POW2, int DEPTH = 0, bool RESIDENT = false, bool SAFEV = false, bool PROBE = false>
 __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
-  if (P.help_select != 0) {                          // two builds were launched for this dispatch: is this the one to run?
-    const bool want_help = P.plan != nullptr && __builtin_amdgcn_readfirstlane((int)P.plan[1]) != 0;
-    if (want_help != HELP) return;
-  }
   __shared__ __attribute__((aligned(16))) uint16_t s_nodes[kLdsCells * 8 + 8];   // + the sentinel slot
   for (uint32_t i = threadIdx.x * 8u; i < P.lds_nodes; i += (uint32_t)TDT_BLOCK * 8u)      // one cell (8 x u16) per lane and trip
     *reinterpret_cast<uint4 *>(&s_nodes[i]) = *reinterpret_cast<const uint4 *>(&P.packed[i]);
@@ -119,17 +85,6 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   __shared__ uint32_t s_grid[kUseGrid ? kGridEntries : 1];
   __shared__ int s_grid_ok;
   if (kUseGrid) build_top_grid(s_nodes, P.lds_nodes, DEPTH, s_grid, &s_grid_ok);
-  constexpr bool help = HELP && !COUNT;
-  __shared__ uint32_t s_pend[help ? TDT_BLOCK : 1];            // helping: ranges of lane i's pixel that are still out
-  __shared__ uint32_t s_ring[help ? kHelpRing : 1][3];         // offered ranges, a ticket queue: sequence word, {owner lane, piece, begin, length}, pixel slot
-  __shared__ uint32_t s_ctl[8];                                // HC_*: ring tickets, idle lanes, tracing lanes, offers waiting
-  if (help) {
-    s_pend[threadIdx.x] = 0u;
-    if (threadIdx.x < kHelpRing) s_ring[threadIdx.x][0] = threadIdx.x;          // slot i is free for ticket i
-    if (threadIdx.x < 8) s_ctl[threadIdx.x] = threadIdx.x == HC_WORKING ? (uint32_t)TDT_BLOCK : 0u;
-    __syncthreads();
-  }
-  const uint32_t lane_gid = blockIdx.x * (uint32_t)TDT_BLOCK + threadIdx.x;
   NodeSource ns;
   ns.lds = s_nodes; ns.lds_nodes = P.lds_nodes; ns.lds_cells = (P.lds_nodes + 7u) >> 3;
   ns.grid = s_grid; ns.grid_ok = kUseGrid ? (__builtin_amdgcn_readfirstlane(s_grid_ok) != 0) : false;
@@ -164,9 +119,6 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   Carry pc;
   pc.root = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}; pc.leaf = pc.root; pc.root_t = 0.f;
   const int s_end = P.spp_begin + P.spp_count;
-  int s_lim = s_end;                                 // where THIS lane's sample range ends (helping cuts ranges)
-  uint32_t h_flags = 0u;                             // HF_*: helper / whose pixel / which piece; pieces out; record freshness
-  uint32_t poll_tick = 0u;
 
   // adaptive event threshold (wave-uniform).  Model: a traversal pass costs C_t issue slots, an event pass C_e
   // whatever the number of lanes it serves; with threshold T about T/2 lanes idle through the traversal
@@ -243,10 +195,8 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     TDT_TICK(0);
     // ------------------------------------------------------------ path events
     const unsigned long long m_trav = __ballot(state == ST_TRAVERSE);
-    const unsigned long long m_wait = help ? __ballot(state == ST_IDLE || state == ST_MERGE) : 0ull;     // (helping) nothing to serve, only to poll
-    const unsigned long long m_event = help ? __ballot(state != ST_TRAVERSE && state != ST_DONE && state != ST_IDLE && state != ST_MERGE)
-                                            : __ballot(state != ST_TRAVERSE && state != ST_DONE);
-    if (m_trav == 0ull && m_event == 0ull && m_wait == 0ull) break;
+    const unsigned long long m_event = __ballot(state != ST_TRAVERSE && state != ST_DONE);
+    if (m_trav == 0ull && m_event == 0ull) break;
     w_steps += (uint32_t)__popcll(m_trav);            // lanes that take the next traversal step
     // run the (long, material-divergent) event code only when enough lanes wait for it (a separate
     // threshold for scatter alone was measured: worse at every setting)
@@ -254,22 +204,17 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     // with the lanes still alive so that the survivors do not wait for company that will never come
     const int n_alive = __popcll(m_trav | m_event);
     const int th_now = n_alive == 64 ? threshold : ((threshold * n_alive) >> 6) + 1;
-    // waiting lanes poll whenever an event pass happens anyway, and every 16th pass otherwise
-    if (help) poll_tick++;
-    const bool poll = help && m_wait != 0ull && (poll_tick & 15u) == 0u;
-    if (!poll && (int)__popcll(m_event) < th_now && m_trav != 0ull) { TDT_TICK(1); continue; }
-    if (help && (m_trav | m_event) == 0ull) __builtin_amdgcn_s_sleep(16);      // only waiting lanes left: poll, politely
+    if ((int)__popcll(m_event) < th_now && m_trav != 0ull) { TDT_TICK(1); continue; }
     TDT_TICK(1);
 
     if (COUNT) evpass_no++;
     if (COUNT) { cnt.event_slots += slot64(); cnt.event_active += (state != ST_TRAVERSE && state != ST_DONE); }
-    lane_work += (state != ST_TRAVERSE && state != ST_DONE && !(help && (state == ST_IDLE || state == ST_MERGE))) ? kCostEvent : 0u;
+    lane_work += (state != ST_TRAVERSE && state != ST_DONE) ? kCostEvent : 0u;
     if (COUNT) lane_E += (state != ST_TRAVERSE && state != ST_DONE) ? 1u : 0u;
     if (state == ST_HIT) {                            // RayColor loop body rc:272-295
       if (COUNT) { cnt.scatter_slots += slot64(); cnt.scatter_active++; }
       const MatRef mat = material_fetch(P, hit_index);
-      if (leaf_rec) { cube_hit_record(r, t_stride, leaf_box_x, leaf_box_y, leaf_box_z, inv_pow_depth, pc.leaf); if (help) h_flags |= HF_LEAF_FRESH; if (COUNT) cnt.leaf_records++; }
-      else if (help && use_leaf && !(h_flags & HF_LEAF_FRESH)) h_flags |= HF_TAINT;      // (helping) a record this range did not write
+      if (leaf_rec) { cube_hit_record(r, t_stride, leaf_box_x, leaf_box_y, leaf_box_z, inv_pow_depth, pc.leaf); if (COUNT) cnt.leaf_records++; }
       loop_count += 1;
       const HitTmp &src = use_leaf ? pc.leaf : pc.root;
       Hit h;
@@ -287,39 +232,6 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       }
     }
     TDT_TICK(2);
-    // end of a pixel: main()'s last lines (rc:249-251) or the running sums + records of a progressive pass
-    auto finish_pixel = [&]() {
-      float4 *dst = reinterpret_cast<float4 *>(P.image) + pix;
-      if (P.accumulate) {
-        *dst = make_float4(sr, sg, sb, 0.f);
-        if (P.carry) {
-          float4 *c = reinterpret_cast<float4 *>(P.carry) + pix * 4;
-          c[0] = make_float4(pc.root.nx, pc.root.ny, pc.root.nz, pc.root.px);
-          c[1] = make_float4(pc.root.py, pc.root.pz, pc.root.ff ? 1.f : 0.f, pc.root_t);
-          c[2] = make_float4(pc.leaf.nx, pc.leaf.ny, pc.leaf.nz, pc.leaf.px);
-          c[3] = make_float4(pc.leaf.py, pc.leaf.pz, pc.leaf.ff ? 1.f : 0.f, 0.f);
-        }
-      } else {
-        const float n = (float)P.samples_per_pixel;   // rc:249-251
-        float4 o;
-        o.x = f_min(f_max(__builtin_sqrtf(sr / n), 0.f), 1.f);
-        o.y = f_min(f_max(__builtin_sqrtf(sg / n), 0.f), 1.f);
-        o.z = f_min(f_max(__builtin_sqrtf(sb / n), 0.f), 1.f);
-        o.w = 1.0f;
-        *dst = o;
-      }
-      if (COUNT && P.pixel_log) {
-        uint32_t *L = P.pixel_log + (size_t)pixel_slot * 8;
-        L[0] = lane_S; L[1] = lane_E; L[2] = pass_no - pixel_pass0; L[3] = (uint32_t)(pixel_rt0 - P.counters[23]);
-        L[4] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - P.counters[23]); L[5] = blockIdx.x * 16 + (threadIdx.x >> 6); L[6] = evpass_no - pixel_evpass0; L[7] = (uint32_t)threshold;
-      }
-      if (COUNT) {
-        const unsigned long long d = (__builtin_amdgcn_s_memrealtime() - pixel_rt0) / 10000ull;   // 0.1 ms bins
-        atomicAdd(&P.counters[32 + 16384 + (wave_drained ? 128 : 0) + (d > 127ull ? 127ull : d)], 1ull);
-      }
-      if (P.slot_cost) P.slot_cost[pixel_slot] = lane_work | 1u;   // a store: nothing to wait for (the sort adds it up)
-    };
-    bool may_offer = false, now_idle = false;
     if (state == ST_END) {                            // rc:297-301, rc:246
       float cr, cg, cb;
       if (loop_count > 0) { cr = ar; cg = ag; cb = ab; }
@@ -328,68 +240,40 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
         const float w = 1.0f + -(0.5f * yp);
         cr = w + 0.25f * yp; cg = w + 0.35f * yp; cb = 1.0f;
       }
-      const bool helper = help && (h_flags & HF_HELPER) != 0u;
-      if (helper) {                                   // (helping) the owner adds this sample's colour, in its turn
-        float *c = P.help_colour + ((size_t)(blockIdx.x * (uint32_t)TDT_BLOCK + ((h_flags >> HF_OWNER_SHIFT) & 1023u)) * kHelpSamples + ((uint32_t)(s - P.spp_begin) & (kHelpSamples - 1))) * 4;
-        st_l2f(c, cr); st_l2f(c + 1, cg); st_l2f(c + 2, cb);
-      }
       sr = sr + cr; sg = sg + cg; sb = sb + cb;
       s++;
-      if (s < (help ? s_lim : s_end) && !(helper && (h_flags & HF_TAINT))) {
-        state = ST_PRIMARY;
-        may_offer = help && !helper && !(h_flags & HF_NO_DONATE) && ((h_flags >> HF_NSEG_SHIFT) & 7u) < (uint32_t)kHelpSegs &&
-                    (s_lim - s) >= 2 * kHelpMinSeg && (s_lim - s) <= kHelpSamples && (s_lim - P.spp_begin) < 2048;
-      } else if (helper) {                            // (helping) the range is done: hand back what the owner cannot know
-        const uint32_t owner = (h_flags >> HF_OWNER_SHIFT) & 1023u;
-        uint32_t *rec = P.help_seg + ((size_t)(blockIdx.x * (uint32_t)TDT_BLOCK + owner) * kHelpSegs + ((h_flags >> HF_SEG_SHIFT) & 7u)) * kHelpSegWords;
-        st_l2(rec + 2, h_flags); st_l2(rec + 3, lane_work);
-        st_l2f(reinterpret_cast<float *>(rec) + 4, pc.root.nx); st_l2f(reinterpret_cast<float *>(rec) + 5, pc.root.ny); st_l2f(reinterpret_cast<float *>(rec) + 6, pc.root.nz);
-        st_l2f(reinterpret_cast<float *>(rec) + 7, pc.root.px); st_l2f(reinterpret_cast<float *>(rec) + 8, pc.root.py); st_l2f(reinterpret_cast<float *>(rec) + 9, pc.root.pz);
-        st_l2(rec + 10, pc.root.ff ? 1u : 0u); st_l2f(reinterpret_cast<float *>(rec) + 11, pc.root_t);
-        st_l2f(reinterpret_cast<float *>(rec) + 12, pc.leaf.nx); st_l2f(reinterpret_cast<float *>(rec) + 13, pc.leaf.ny); st_l2f(reinterpret_cast<float *>(rec) + 14, pc.leaf.nz);
-        st_l2f(reinterpret_cast<float *>(rec) + 15, pc.leaf.px); st_l2f(reinterpret_cast<float *>(rec) + 16, pc.leaf.py); st_l2f(reinterpret_cast<float *>(rec) + 17, pc.leaf.pz);
-        st_l2(rec + 18, pc.leaf.ff ? 1u : 0u);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the stores above, then the count below
-        atomicSub(&s_pend[owner], 1u);
-        h_flags = 0u;
-        state = ST_IDLE; now_idle = true;
-      } else if (help && ((h_flags >> HF_NSEG_SHIFT) & 7u) != 0u) {
-        state = ST_MERGE;                             // (helping) own samples done; pieces of this pixel are still out
-        atomicSub(&s_ctl[HC_WORKING], 1u);
-      } else {
-        finish_pixel();
-        state = ST_FETCH;
-      }
-    }
-    if (help) {
-      // (helping) offer: ONE lane per wave and pass, and only while more lanes are idle than offers wait
-      const unsigned long long m_offer = __ballot(may_offer);
-      if (m_offer != 0ull) {
-        const uint32_t hungry = *reinterpret_cast<volatile uint32_t *>(&s_ctl[HC_HUNGRY]), waiting = *reinterpret_cast<volatile uint32_t *>(&s_ctl[HC_ITEMS]);
-        if (hungry > waiting && waiting < kHelpRing / 2u && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m_offer)) {
-          uint32_t nseg = (h_flags >> HF_NSEG_SHIFT) & 7u;
-          const int rem = s_lim - s;
-          int n = (int)(hungry - waiting);
-          if (n > kHelpSegs - (int)nseg) n = kHelpSegs - (int)nseg;
-          if (n > rem / kHelpMinSeg - 1) n = rem / kHelpMinSeg - 1;
-          const int piece = rem / (n + 1);
-          int e = s_lim;
-          for (int j = 0; j < n; j++) {
-            const uint32_t ticket = atomicAdd(&s_ctl[HC_TAIL], 1u), slot = ticket & (kHelpRing - 1u);
-            while (*reinterpret_cast<volatile uint32_t *>(&s_ring[slot][0]) != ticket) __builtin_amdgcn_s_sleep(1);   // (its last taker is mid-read in another wave)
-            const int bgn = e - piece;
-            s_ring[slot][1] = threadIdx.x | (nseg << 10) | ((uint32_t)(bgn - P.spp_begin) << 13) | ((uint32_t)piece << 24);
-            s_ring[slot][2] = pixel_slot;
-            atomicAdd(&s_pend[threadIdx.x], 1u);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            *reinterpret_cast<volatile uint32_t *>(&s_ring[slot][0]) = ticket + 1u;          // published
-            atomicAdd(&s_ctl[HC_ITEMS], 1u);
-            nseg++; e = bgn;
+      if (s < s_end) state = ST_PRIMARY;
+      else {
+        float4 *dst = reinterpret_cast<float4 *>(P.image) + pix;
+        if (P.accumulate) {
+          *dst = make_float4(sr, sg, sb, 0.f);
+          if (P.carry) {
+            float4 *c = reinterpret_cast<float4 *>(P.carry) + pix * 4;
+            c[0] = make_float4(pc.root.nx, pc.root.ny, pc.root.nz, pc.root.px);
+            c[1] = make_float4(pc.root.py, pc.root.pz, pc.root.ff ? 1.f : 0.f, pc.root_t);
+            c[2] = make_float4(pc.leaf.nx, pc.leaf.ny, pc.leaf.nz, pc.leaf.px);
+            c[3] = make_float4(pc.leaf.py, pc.leaf.pz, pc.leaf.ff ? 1.f : 0.f, 0.f);
           }
-          atomicAdd(&P.help_stats[0], (uint32_t)((s_lim - e) / piece));
-          s_lim = e;
-          h_flags = (h_flags & ~(7u << HF_NSEG_SHIFT)) | (nseg << HF_NSEG_SHIFT);
+        } else {
+          const float n = (float)P.samples_per_pixel;   // rc:249-251
+          float4 o;
+          o.x = f_min(f_max(__builtin_sqrtf(sr / n), 0.f), 1.f);
+          o.y = f_min(f_max(__builtin_sqrtf(sg / n), 0.f), 1.f);
+          o.z = f_min(f_max(__builtin_sqrtf(sb / n), 0.f), 1.f);
+          o.w = 1.0f;
+          *dst = o;
         }
+        if (COUNT && P.pixel_log) {
+          uint32_t *L = P.pixel_log + (size_t)pixel_slot * 8;
+          L[0] = lane_S; L[1] = lane_E; L[2] = pass_no - pixel_pass0; L[3] = (uint32_t)(pixel_rt0 - P.counters[23]);
+          L[4] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - P.counters[23]); L[5] = blockIdx.x * 16 + (threadIdx.x >> 6); L[6] = evpass_no - pixel_evpass0; L[7] = (uint32_t)threshold;
+        }
+        if (COUNT) {
+          const unsigned long long d = (__builtin_amdgcn_s_memrealtime() - pixel_rt0) / 10000ull;   // 0.1 ms bins
+          atomicAdd(&P.counters[32 + 16384 + (wave_drained ? 128 : 0) + (d > 127ull ? 127ull : d)], 1ull);
+        }
+        if (P.slot_cost) P.slot_cost[pixel_slot] = lane_work | 1u;   // a store: nothing to wait for (the sort adds it up)
+        state = ST_FETCH;
       }
     }
     TDT_TICK(3);
@@ -423,17 +307,13 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
         if (served) {
           want = false;
           const uint32_t q = got;
-          if (q == 0xFFFFFFFFu) {
-            state = help ? ST_IDLE : ST_DONE; now_idle = help;       // (helping) stay and look for ranges to trace
-            if (COUNT) atomicMin(&P.counters[22], __builtin_amdgcn_s_memrealtime());
-          }
+          if (q == 0xFFFFFFFFu) { state = ST_DONE; if (COUNT) atomicMin(&P.counters[22], __builtin_amdgcn_s_memrealtime()); }
           else {
             if (COUNT) { pixel_rt0 = __builtin_amdgcn_s_memrealtime(); lane_S = 0; lane_E = 0; pixel_pass0 = pass_no; pixel_evpass0 = evpass_no; }
             bool inside;
             pixel_slot = q;
             decode_pixel(P, (int)(pixel_slot >> 10), pixel_slot & 1023u, x, y, pix, inside);
             lane_work = 0u;
-            if (help) { s_lim = s_end; h_flags = 0u; }
             if (inside) {                             // outside the covered image: ask again next time
               n_pixels++;
               sr = 0.f; sg = 0.f; sb = 0.f; s = P.spp_begin;
@@ -456,89 +336,6 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
               }
             }
           }
-        }
-      }
-    }
-    if (help && m_wait_or_new(state, now_idle)) {
-      // (helping) lanes that just ran out of work: count them (one LDS atomic pair per wave)
-      const unsigned long long m_new = __ballot(now_idle);
-      if (m_new != 0ull && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m_new)) {
-        atomicAdd(&s_ctl[HC_HUNGRY], (uint32_t)__popcll(m_new));
-        atomicSub(&s_ctl[HC_WORKING], (uint32_t)__popcll(m_new));
-      }
-      // merge: the owner's pieces are back — add their colours in sample order, take over the records they wrote
-      if (state == ST_MERGE && *reinterpret_cast<volatile uint32_t *>(&s_pend[threadIdx.x]) == 0u) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        bool again = false;
-        for (int k = (int)((h_flags >> HF_NSEG_SHIFT) & 7u) - 1; k >= 0; k--) {      // pieces were cut from the top: the last one is the lowest
-          const uint32_t *rec = P.help_seg + ((size_t)lane_gid * kHelpSegs + (uint32_t)k) * kHelpSegWords;
-          const float *recf = reinterpret_cast<const float *>(rec);
-          const int bgn = (int)ld_l2(rec), end = (int)ld_l2(rec + 1);
-          const uint32_t fl = ld_l2(rec + 2);
-          if (fl & HF_TAINT) {                        // it read a record it did not write: trace from there on again, here, with the right ones
-            s = bgn; again = true;
-            atomicAdd(&P.help_stats[2], 1u);
-            break;
-          }
-          for (int q = bgn; q < end; q++) {
-            const float *c = P.help_colour + ((size_t)lane_gid * kHelpSamples + ((uint32_t)(q - P.spp_begin) & (kHelpSamples - 1))) * 4;
-            const float c0 = ld_l2f(c), c1 = ld_l2f(c + 1), c2 = ld_l2f(c + 2);
-            sr = sr + c0; sg = sg + c1; sb = sb + c2;
-          }
-          lane_work += ld_l2(rec + 3);
-          if (fl & HF_ROOT_FRESH) {
-            pc.root = {ld_l2f(recf + 4), ld_l2f(recf + 5), ld_l2f(recf + 6), ld_l2f(recf + 7), ld_l2f(recf + 8), ld_l2f(recf + 9), ld_l2(rec + 10) != 0u};
-            pc.root_t = ld_l2f(recf + 11);
-          }
-          if (fl & HF_LEAF_FRESH)
-            pc.leaf = {ld_l2f(recf + 12), ld_l2f(recf + 13), ld_l2f(recf + 14), ld_l2f(recf + 15), ld_l2f(recf + 16), ld_l2f(recf + 17), ld_l2(rec + 18) != 0u};
-        }
-        if (again) {
-          s_lim = s_end; h_flags = HF_NO_DONATE | HF_ROOT_FRESH | HF_LEAF_FRESH;
-          atomicAdd(&s_ctl[HC_WORKING], 1u);
-          state = ST_PRIMARY;
-        } else {
-          finish_pixel();
-          h_flags = 0u;
-          atomicAdd(&s_ctl[HC_HUNGRY], 1u);
-          atomicAdd(&P.help_stats[3], 1u);
-          state = ST_IDLE;
-        }
-      }
-      // help: an idle lane takes an offered range — or retires when nobody in the block is tracing and nothing is offered
-      const unsigned long long m_idle = __ballot(state == ST_IDLE);
-      if (m_idle != 0ull) {
-        const uint32_t working = *reinterpret_cast<volatile uint32_t *>(&s_ctl[HC_WORKING]);      // read BEFORE the offers: only a tracing lane posts
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const uint32_t waiting = *reinterpret_cast<volatile uint32_t *>(&s_ctl[HC_ITEMS]);
-        if (waiting != 0u) {
-          if (state == ST_IDLE) {
-            // reserve one waiting offer (decrement-if-positive), then take the next ticket: offers are served in order
-            uint32_t w = waiting; bool got = false;
-            while (w != 0u) { const uint32_t old = atomicCAS(&s_ctl[HC_ITEMS], w, w - 1u); if (old == w) { got = true; break; } w = old; }
-            if (got) {
-              const uint32_t ticket = atomicAdd(&s_ctl[HC_HEAD], 1u), slot = ticket & (kHelpRing - 1u);
-              while (*reinterpret_cast<volatile uint32_t *>(&s_ring[slot][0]) != ticket + 1u) __builtin_amdgcn_s_sleep(1);   // (its offerer is mid-write in another wave)
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-              const uint32_t item = *reinterpret_cast<volatile uint32_t *>(&s_ring[slot][1]);
-              pixel_slot = *reinterpret_cast<volatile uint32_t *>(&s_ring[slot][2]);
-              *reinterpret_cast<volatile uint32_t *>(&s_ring[slot][0]) = ticket + kHelpRing;    // free for the ticket one lap on
-              atomicSub(&s_ctl[HC_HUNGRY], 1u); atomicAdd(&s_ctl[HC_WORKING], 1u);
-              atomicAdd(&P.help_stats[1], 1u);
-              bool inside;
-              decode_pixel(P, (int)(pixel_slot >> 10), pixel_slot & 1023u, x, y, pix, inside);
-              s = P.spp_begin + (int)((item >> 13) & 2047u);
-              s_lim = s + (int)((item >> 24) & 127u);
-              h_flags = HF_HELPER | ((item & 1023u) << HF_OWNER_SHIFT) | (((item >> 10) & 7u) << HF_SEG_SHIFT);
-              uint32_t *rec = P.help_seg + ((size_t)(blockIdx.x * (uint32_t)TDT_BLOCK + (item & 1023u)) * kHelpSegs + ((item >> 10) & 7u)) * kHelpSegWords;
-              st_l2(rec, (uint32_t)s); st_l2(rec + 1, (uint32_t)s_lim);
-              lane_work = 0u; sr = 0.f; sg = 0.f; sb = 0.f;
-              pc.root = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}; pc.leaf = pc.root; pc.root_t = 0.f;
-              state = ST_PRIMARY;
-            }
-          }
-        } else if (working == 0u) {
-          if (state == ST_IDLE) state = ST_DONE;
         }
       }
     }
@@ -574,8 +371,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
           cube_hit_record(r, t_enter, P.min_x, P.min_y, P.min_z, P.scale, pc.root);
           pc.root_t = t_enter;
           t_octree_max = t_exit;
-          if (help) h_flags |= HF_ROOT_FRESH;
-        } else if (help && !(h_flags & HF_ROOT_FRESH)) h_flags |= HF_TAINT;    // (helping) the root call site's old record / t is used below
+        }
         t_stride = pc.root_t;
         inv_pow_depth = 0.5f;
         it = 0;
@@ -785,9 +581,7 @@ __global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restric
 // slot parked in a batch starts late, which costs more than it gains once single pixels are long against the frame
 // (1080p/512^3, where a pixel can take 40 % of the frame: +4 %).  From the cost histogram: f = c_hi * lanes / sum(cost) is the
 // share of the frame a pixel of the 99.9th cost percentile occupies its lane for; exact drawing when f > max_share.
-// plan[1] = 1 -> the build with the end-of-frame helping runs this dispatch (trace_kernel "Helping"): worth its overhead only
-// where single pixels are long against the frame, by the same measure with its own threshold.
-__global__ __launch_bounds__(512) void order_plan_kernel(const uint32_t *__restrict__ hist, uint32_t g, uint32_t lanes, float max_share, float help_share,
+__global__ __launch_bounds__(512) void order_plan_kernel(const uint32_t *__restrict__ hist, uint32_t g, uint32_t lanes, float max_share,
                                                          uint32_t *__restrict__ plan) {
   __shared__ float s_sum[512];
   __shared__ uint32_t s_cnt[512];
@@ -809,7 +603,6 @@ __global__ __launch_bounds__(512) void order_plan_kernel(const uint32_t *__restr
     const uint32_t idx = (bins - 1u) - hi_bin, e = idx >> g, frac = idx & ((1u << g) - 1u);
     const float c_hi = __builtin_ldexpf(1.0f + (float)frac / (float)(1u << g), (int)e);
     plan[0] = (total > 0.f && c_hi * (float)lanes > max_share * total) ? 1u : 0u;
-    plan[1] = (total > 0.f && c_hi * (float)lanes > help_share * total) ? 1u : 0u;
   }
 }
 
@@ -998,17 +791,6 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
       ctx->packed_of = cb; ctx->packed_version = cb->version;
     }
     P.packed = ctx->packed; P.queue = ctx->queue;
-    // helping (see trace_kernel): per-lane side buffers, allocated once; not for instrumented launches (their totals count lanes' own work)
-    if (!ctx->no_help && !counts_out && mode == 1 && !ctx->probe_launch) {
-      const size_t lanes = (size_t)ctx->num_cus * TDT_BLOCKS_PER_CU * TDT_BLOCK;
-      if (!ctx->help_colour) TDT_HIP(ctx, hipMalloc((void **)&ctx->help_colour, lanes * tdt::kHelpSamples * 4 * sizeof(float)));
-      if (!ctx->help_seg) {
-        TDT_HIP(ctx, hipMalloc((void **)&ctx->help_seg, (lanes * tdt::kHelpSegs * tdt::kHelpSegWords + 4) * sizeof(uint32_t)));
-        TDT_HIP(ctx, hipMemsetAsync(ctx->help_seg + lanes * tdt::kHelpSegs * tdt::kHelpSegWords, 0, 4 * sizeof(uint32_t), ctx->stream));
-      }
-      P.help_colour = ctx->help_colour; P.help_seg = ctx->help_seg;
-      P.help_stats = ctx->help_seg + lanes * tdt::kHelpSegs * tdt::kHelpSegWords;      // 4 running totals behind the records
-    }
     // cost-feedback hand-out order (see order_scatter_kernel); TDT_NO_COST_ORDER=1: image order
     if (!ctx->no_cost_order) {
       if (ctx->tile_capacity < (uint32_t)t.owned) {
@@ -1019,7 +801,7 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
         TDT_HIP(ctx, hipMalloc((void **)&ctx->slot_cost, (size_t)t.owned * 1024 * sizeof(uint32_t)));
         TDT_HIP(ctx, hipMalloc((void **)&ctx->slot_order, (size_t)t.owned * 1024 * sizeof(uint32_t)));
         TDT_HIP(ctx, hipMalloc((void **)&ctx->slot_acc, (size_t)t.owned * 1024 * sizeof(uint32_t)));
-        if (!ctx->order_hist) TDT_HIP(ctx, hipMalloc((void **)&ctx->order_hist, 1032 * sizeof(uint32_t)));
+        if (!ctx->order_hist) TDT_HIP(ctx, hipMalloc((void **)&ctx->order_hist, 1028 * sizeof(uint32_t)));
         ctx->tile_capacity = (uint32_t)t.owned;
       }
       // what this dispatch traces: if it equals what the recorded costs were measured on (a still camera: progressive
@@ -1048,8 +830,8 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
         {
           const float max_share = ctx->max_share;
           const uint32_t lanes = (uint32_t)ctx->num_cus * TDT_BLOCKS_PER_CU * TDT_BLOCK;
-          if (!smooth) hipLaunchKernelGGL(tdt::order_plan_kernel, dim3(1), dim3(512), 0, ctx->stream, ctx->order_hist, og, lanes, max_share, ctx->help_share, ctx->order_hist + 1024);
-          else TDT_HIP(ctx, hipMemsetAsync(ctx->order_hist + 1024, 0, 2 * sizeof(uint32_t), ctx->stream));
+          if (!smooth) hipLaunchKernelGGL(tdt::order_plan_kernel, dim3(1), dim3(512), 0, ctx->stream, ctx->order_hist, og, lanes, max_share, ctx->order_hist + 1024);
+          else TDT_HIP(ctx, hipMemsetAsync(ctx->order_hist + 1024, 0, sizeof(uint32_t), ctx->stream));
           P.plan = ctx->order_hist + 1024;
         }
         hipLaunchKernelGGL(tdt::order_scatter_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, ctx->slot_acc, n_slots,
@@ -1084,15 +866,8 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     bool launched = false;
     P.accumulate = mode == 1 ? 1 : 0;
     if (mode != 2 && !counts_out && pow2 && safev && !ctx->no_specialise) {
-      // accumulate-mode launches that follow a per-pixel sort (the main launch of a two-phase frame, progressive passes) go out
-      // as TWO builds: plan[1] — the device's own reading of the cost histogram — picks the one with the end-of-frame helping
-      // (trace_kernel "Helping") or the plain one; the other returns at once.  Replays of a frame (mode 0) know every pixel's
-      // cost exactly and have no tail worth the helping build's overhead.
-      const bool both = P.help_colour != nullptr && P.plan != nullptr;
-      P.help_select = both ? 1 : 0;
 #define TDT_SPEC(D, R) if (ctx->probe_launch) hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, R, true, true>), grid, block, 0, ctx->stream, P); \
-                       else { hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, R, true>), grid, block, 0, ctx->stream, P); \
-                              if (both) hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, R, true, false, true>), grid, block, 0, ctx->stream, P); } \
+                       else hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, R, true>), grid, block, 0, ctx->stream, P); \
                        launched = true; break
       if (resident) switch (P.max_depth) {
         case 3: TDT_SPEC(3, true); case 4: TDT_SPEC(4, true); case 5: TDT_SPEC(5, true); case 6: TDT_SPEC(6, true);
@@ -1163,10 +938,8 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
     const char *fs = getenv("TDT_ORDER_SMOOTH"); ctx->force_smooth = fs ? atoi(fs) : -1;
     ctx->no_cost_accum = getenv("TDT_NO_COST_ACCUM") != nullptr;
     ctx->no_two_phase = getenv("TDT_NO_TWO_PHASE") != nullptr;
-    ctx->no_help = getenv("TDT_NO_HELP") != nullptr;
     const char *ms = getenv("TDT_MAX_SHARE"); ctx->max_share = ms ? (float)atof(ms) : 0.25f;
-    const char *ob = getenv("TDT_ORDER_BLEND"); ctx->order_blend = ob ? (float)atof(ob) : 0.5f;
-    const char *hs = getenv("TDT_HELP_SHARE"); ctx->help_share = hs ? (float)atof(hs) : 0.25f; }
+    const char *ob = getenv("TDT_ORDER_BLEND"); ctx->order_blend = ob ? (float)atof(ob) : 0.5f; }
   ctx->scan = nullptr; ctx->max_parent_value = ctx->max_any_value = 0xFFFFFFFFu;
   { hipDeviceProp_t prop; ctx->num_cus = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
   { const char *fg = getenv("TDT_FORCE_GENERIC"); ctx->force_generic = fg && fg[0] == '1';
@@ -1202,8 +975,6 @@ void tdt_ctx_destroy(tdt_ctx *ctx) {
   if (ctx->pixel_log) (void)hipFree(ctx->pixel_log);
   if (ctx->present) (void)hipFree(ctx->present);
   if (ctx->frame_carry) (void)hipFree(ctx->frame_carry);
-  if (ctx->help_colour) (void)hipFree(ctx->help_colour);
-  if (ctx->help_seg) (void)hipFree(ctx->help_seg);
   if (ctx->phase_timing) for (auto &e : ctx->phase_ev) (void)hipEventDestroy(e);
   tdt::edit_scratch_destroy(ctx);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -1593,28 +1364,6 @@ int tdt_forget_costs(tdt_ctx *ctx) {
   if (!ctx) return TDT_ERR_INVALID_VALUE;
   if (ctx->multi) return tdt::multi_forget_costs(ctx);
   ctx->cost_tiles = 0; ctx->cost_dispatches = 0;      // launch(): "no usable history" -> image order, fresh cost arrays
-  return TDT_OK;
-}
-
-int tdt_debug_help_stats(tdt_ctx *ctx, uint64_t out[4]) {
-  if (!ctx || !out) return TDT_ERR_INVALID_VALUE;
-  for (int i = 0; i < 4; i++) out[i] = 0;
-  if (ctx->multi) {
-    for (int i = 0; i < tdt_ctx_device_count(ctx); i++) {
-      uint64_t part[4];
-      const int rc = tdt_debug_help_stats(tdt::multi_member(ctx, i), part);
-      if (rc != TDT_OK) return rc;
-      for (int j = 0; j < 4; j++) out[j] += part[j];
-    }
-    return TDT_OK;
-  }
-  if (!ctx->help_seg) return TDT_OK;
-  TDT_HIP(ctx, hipSetDevice(ctx->device));
-  uint32_t v[4];
-  const size_t lanes = (size_t)ctx->num_cus * TDT_BLOCKS_PER_CU * TDT_BLOCK;
-  TDT_HIP(ctx, hipMemcpyAsync(v, ctx->help_seg + lanes * tdt::kHelpSegs * tdt::kHelpSegWords, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
-  TDT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  for (int i = 0; i < 4; i++) out[i] = v[i];
   return TDT_OK;
 }
 

@@ -311,21 +311,6 @@ TDT_DEV void build_top_grid(const uint16_t *lds, uint32_t lds_nodes, int depth, 
   __syncthreads();
 }
 
-// ---- helping (end of frame; see trace_kernel) ------------------------------------------------------------------------
-constexpr int kHelpSamples = 64;      // a pixel's donated sample ranges lie within a window of this many samples
-constexpr int kHelpSegs = 7;          // ranges one pixel can have out at a time
-constexpr int kHelpSegWords = 20;     // record a helper hands back: begin, end, flags, work, root record (7) + root t, leaf record (7), pad
-constexpr int kHelpMinSeg = 4;        // samples: a range is not cut finer than this
-constexpr uint32_t kHelpRing = 256;   // LDS ring of offered ranges per block
-enum : uint32_t { HF_HELPER = 1u, HF_OWNER_SHIFT = 1, HF_SEG_SHIFT = 11, HF_NSEG_SHIFT = 16, HF_NO_DONATE = 1u << 20,
-                  HF_ROOT_FRESH = 1u << 24, HF_LEAF_FRESH = 1u << 25, HF_TAINT = 1u << 26 };
-enum : int { HC_TAIL = 0, HC_HEAD = 1, HC_HUNGRY = 2, HC_WORKING = 3, HC_ITEMS = 4 };
-// loads / stores that bypass the CU's vector L1 (sc1: served by the XCD's L2, which every wave of a work-group shares)
-TDT_DEV uint32_t ld_l2(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-TDT_DEV void st_l2(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-TDT_DEV float ld_l2f(const float *p) { return __uint_as_float(ld_l2(reinterpret_cast<const uint32_t *>(p))); }
-TDT_DEV void st_l2f(float *p, float v) { st_l2(reinterpret_cast<uint32_t *>(p), __float_as_uint(v)); }
-
 // a pixel's cost for the hand-out order of the next dispatch (tdt_rt.hip, "Cost-feedback scheduling"):
 // tree levels visited + kCostStep per traversal step + kCostEvent per path event (measured plateau 24..128)
 constexpr uint32_t kCostStep = 3, kCostEvent = 64;

@@ -37,11 +37,6 @@ struct TraceParams {
   int32_t accumulate;             // 0: main() as written (resolve and store); 1: add the samples to the running sums in `image`
   int32_t mode;                // 0 render (sum, sqrt, clamp, store), 1 accumulate into image, 2 resolve
   int32_t total_spp;           // resolve divisor
-  // end-of-frame helping (see trace_kernel "Helping"): per-lane side buffers in HBM
-  float *help_colour;          // [grid lanes][kHelpSamples] RGBA: colours of samples a helper traced for the pixel of that lane
-  uint32_t *help_seg;          // [grid lanes][kHelpSegs][kHelpSegWords]: what a helper hands back besides the colours
-  uint32_t *help_stats;        // 4 running totals: pieces offered, taken, redone (tainted), pixels merged
-  int32_t help_select;         // 1: this dispatch launched the plain AND the helping build: plan[1] says which one runs
   int32_t event_threshold;     // > 0: fixed number of lanes that must wait for the event code; 0: adaptive
   float event_k;               // adaptive threshold: r = C_t / (2 C_e) of the model in trace_kernel
 };

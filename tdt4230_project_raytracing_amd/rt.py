@@ -66,7 +66,6 @@ SYMBOLS = [
     ("tdt_dispatch_counted_range", _I, [_P, _I, _I, _I, _I, _I, _P, ctypes.POINTER(ctypes.c_uint64)]),
     ("tdt_forget_costs", _I, [_P]),
     ("tdt_debug_phase_timing", _I, [_P, _I, ctypes.POINTER(ctypes.c_float)]),
-    ("tdt_debug_help_stats", _I, [_P, ctypes.POINTER(ctypes.c_uint64)]),
     ("tdt_debug_multi_timing", _I, [_P, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
     ("tdt_debug_multi_transport", ctypes.c_char_p, [_P]),
     ("tdt_octree_build_cells", _I, [_P, _P, _S, _I, _PP, ctypes.POINTER(ctypes.c_uint32)]),
@@ -137,12 +136,6 @@ class Context:
     def forget_costs(self):
         """Drop the per-pixel cost history: the next dispatch_compute is scheduled like a context's first frame."""
         self.check(lib().tdt_forget_costs(self.h))
-
-    def help_stats(self):
-        """End-of-frame helping, running totals: sample ranges offered / taken / traced again by the owner, pixels merged."""
-        v = (ctypes.c_uint64 * 4)()
-        self.check(lib().tdt_debug_help_stats(self.h, v))
-        return dict(zip(("offered", "taken", "redone", "merged"), [int(x) for x in v]))
 
     def phase_timing(self, enable=True):
         """(probe_ms, main_ms, resolve_ms) of the last dispatch_compute (blocks); switches the recording on / off."""
