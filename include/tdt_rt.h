@@ -244,9 +244,10 @@ int tdt_debug_wave_ends(tdt_ctx *ctx, uint64_t *out, int n);
 int tdt_debug_pixel_log(tdt_ctx *ctx, uint32_t *out, size_t n_u32);
 /* exhaustive (all 2^32 inputs) check of the kernels' short correctly-rounded rcp (0) / sqrt (1) /
  * rsq (2) forms against the IEEE expressions, of v_fract_f32 against x - floor(x) for x >= 0 (4), and of the top-level
- * jump table's claim (5): for every coordinate in [0,1) outside its bands and every cell index < 128 the x decision of
- * treeLookup's first three levels is the coordinate's binary digit.  *mismatches must be 0.  Modes 3 and 6 check the
- * harness: the raw reciprocal seed, and the claim without the bands, must fail. */
+ * jump tables' claim (5: the 4-level table of LDS-resident trees, 7: the 5-level table of the others): for every coordinate
+ * in [0,1) outside the table's bands and every cell index below its bounds (128 / 1024 / 8192 by level) the x decision of
+ * treeLookup's first four / five levels is the coordinate's binary digit.  *mismatches must be 0.  Modes 3, 6 and 8 check
+ * the harness: the raw reciprocal seed, and the claims without the bands, must fail. */
 int tdt_selftest(tdt_ctx *ctx, int which, uint64_t *mismatches);
 
 #ifdef __cplusplus

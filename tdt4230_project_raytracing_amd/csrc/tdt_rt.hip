@@ -81,14 +81,15 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   if (threadIdx.x < 16 && P.lds_nodes + threadIdx.x < ((P.lds_nodes + 7u) & ~7u) + 8u)
     s_nodes[P.lds_nodes + threadIdx.x] = (uint16_t)((RESIDENT && POW2) ? 0u : kPackedEscape);
   __syncthreads();
-  constexpr bool kUseGrid = !COUNT && POW2 && SAFEV && DEPTH >= kGridLevels;   // see build_top_grid
-  __shared__ uint32_t s_grid[kUseGrid ? kGridEntries : 1];
+  constexpr int GL = RESIDENT ? 4 : 5;                                 // levels of the top-level jump table (see Grid<GL>)
+  constexpr bool kUseGrid = !COUNT && POW2 && SAFEV && DEPTH >= GL;   // see build_top_grid
+  __shared__ typename Grid<GL>::Entry s_grid[kUseGrid ? Grid<GL>::kEntries : 1];
   __shared__ int s_grid_ok;
-  if (kUseGrid) build_top_grid(s_nodes, P.lds_nodes, DEPTH, s_grid, &s_grid_ok);
+  if (kUseGrid) build_top_grid<GL>(s_nodes, P.lds_nodes, DEPTH, s_grid, &s_grid_ok);
   NodeSource ns;
   ns.lds = s_nodes; ns.lds_nodes = P.lds_nodes; ns.lds_cells = (P.lds_nodes + 7u) >> 3;
   ns.grid = s_grid; ns.grid_ok = kUseGrid ? (__builtin_amdgcn_readfirstlane(s_grid_ok) != 0) : false;
-  ns.grid_band = ns.grid_ok ? kGridBand : 2.0f;
+  ns.grid_band = ns.grid_ok ? Grid<GL>::kBand : 2.0f;
   ns.cells = __builtin_amdgcn_make_buffer_rsrc((void *)P.cells, 0, (int)((P.cells_dwords >> 1) << 3), 0x00020000);
   const uint32_t total_slots = (uint32_t)P.owned_tiles * 1024u;
 
@@ -452,17 +453,19 @@ __global__ __launch_bounds__(256) void selftest_kernel(int which, unsigned long 
   for (uint32_t k = 0; k < (0xFFFFFFFFu / stride) + 1u; k++, i += stride) {
     if (k > 0 && i < stride) break;                   // wrapped
     const float x = __uint_as_float(i);
-    if (which == 5 || which == 6) {
+    if (which >= 5 && which <= 8) {
       // build_top_grid's claim, for EVERY coordinate c in [0,1) and every cell index below grid_v_bound: outside the
-      // bands (|2^L c - rint(2^L c)| > kGridBand) the x decision of levels 1..L is the plain binary digit of c and never
-      // 2v+2.  which == 6 checks the harness: with the band test removed the claim must fail.
+      // bands (|2^L c - rint(2^L c)| > Grid<L>::kBand) the x decision of levels 1..L is the plain binary digit of c and never
+      // 2v+2.  5: the 4-level table, 7: the 5-level table; 6 / 8 check the harness: with the band test removed the claim must fail.
       if (!(x >= 0.0f && x < 1.0f)) continue;
-      const float tg = x * (float)(1 << kGridLevels);
-      if (which == 5 && !(__builtin_fabsf(tg - __builtin_rintf(tg)) > kGridBand)) continue;
+      const int L = which >= 7 ? 5 : 4;
+      const float band = which >= 7 ? Grid<5>::kBand : Grid<4>::kBand;
+      const float tg = x * (float)(1 << L);
+      if ((which == 5 || which == 7) && !(__builtin_fabsf(tg - __builtin_rintf(tg)) > band)) continue;
       const uint32_t xg = (uint32_t)tg;
-      for (int l = 1; l <= kGridLevels; l++) {
+      for (int l = 1; l <= L; l++) {
         const float f = l == 1 ? x : f_fract_nonneg(x * (float)(1 << (l - 1)));
-        const uint32_t digit = (xg >> (kGridLevels - l)) & 1u;
+        const uint32_t digit = (xg >> (L - l)) & 1u;
         const uint32_t vmax = l == 1 ? 1u : grid_v_bound(l - 1);          // the cell index this level's decision uses
         for (uint32_t v = 0; v < vmax; v++) {
           const float fv = (float)v, q = (fv + f) - fv;
@@ -1411,7 +1414,7 @@ int tdt_debug_wave_ends(tdt_ctx *ctx, uint64_t *out, int n) {
 /* Exhaustive self-test of the kernels' short correctly-rounded rcp / sqrt / rsq forms against the
  * IEEE expressions on all 2^32 inputs; *mismatches must come back 0 (which: 0 rcp, 1 sqrt, 2 rsq). */
 int tdt_selftest(tdt_ctx *ctx, int which, uint64_t *mismatches) {
-  if (!ctx || !mismatches || which < 0 || which > 6) return TDT_ERR_INVALID_VALUE;
+  if (!ctx || !mismatches || which < 0 || which > 8) return TDT_ERR_INVALID_VALUE;
   TDT_HIP(ctx, hipSetDevice(ctx->device));
   if (!ctx->counters) TDT_HIP(ctx, hipMalloc((void **)&ctx->counters, (32 + 16384 + 256) * sizeof(unsigned long long)));
   TDT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));

@@ -155,7 +155,7 @@ struct NodeSource {
   const uint16_t *lds;                                // LDS table
   uint32_t lds_nodes;                                 // valid entries
   uint32_t lds_cells;                                 // cells they make up (the last may be partial): index of the sentinel cell
-  const uint32_t *grid;                               // top-level jump table (see build_top_grid), or unusable when !grid_ok
+  const void *grid;                                   // top-level jump table (Grid<GL>::Entry[], see build_top_grid), or unusable when !grid_ok
   bool grid_ok; float grid_band;                      // grid_band = kGridBand, or 2 when the table is unusable
   __amdgpu_buffer_rsrc_t cells;                       // raw buffer over the cells payload (8-byte granules)
 };
@@ -284,15 +284,48 @@ struct NodeMemo { uint32_t key[CL]; uint32_t val[CL]; };
 // probe for a node of a depth >= 5 cell almost never hits; it is only a cache, so skipping it is always correct
 // (4K/256^3: 292 -> 280 ms, 1080p/512^3: 166 -> 153 ms; from level 5 on: 286 / 154 ms).
 constexpr int kNoProbeFrom = 6;
-constexpr int kGridLevels = 4;
-constexpr uint32_t kGridEntries = 1u << (3 * kGridLevels);
-constexpr float kGridBand = 0x1.0p-12f;
-TDT_DEV uint32_t grid_v_bound(int level) { return level < 3 ? 128u : 1024u; }   // bound on the cell index a level-`level` PARENT may hold
-TDT_DEV void build_top_grid(const uint16_t *lds, uint32_t lds_nodes, int depth, uint32_t *grid, int *grid_ok) {
+// Levels per table: FOUR (4096 32-bit entries, 16 KB) for trees that are wholly LDS-resident — their levels are one ds_read_b128
+// and ~20 instructions each, and a fifth level in the table was 1 % slower than walking it (a 3-level table had been 4 % slower
+// than 4) — and FIVE (round 2: 32768 entries of 16 bits, 64 KB beside the 82 KB node table: 146 of the CU's 160 KB) for trees
+// that are not, whose level 5 otherwise costs an LDS probe, a memo compare and sometimes an L2 round trip (4K/256^3: -1.1 %,
+// 1080p/512^3: -5.8 %).  The cell index the level-5 decision uses can reach 8191 (levels 1-4 hold at most 585 cells, level 5
+// up to 4096 more), where ulp(v + f) = 2^-11: the bands around the integers of 32 c are 2^-11 wide, 2^-10 of all coordinates
+// fall into them (a wave with a lane inside one — about 5 % of the steps — walks the levels one by one), and the exhaustive
+// check (tdt_selftest 5 / 7) covers every coordinate x every cell index below the bounds x every level of the table.
+TDT_DEV uint32_t grid_v_bound(int level) { return level < 3 ? 128u : (level == 3 ? 1024u : 8192u); }   // bound on the cell index a level-`level` PARENT may hold
+template <int GL> struct Grid;
+template <> struct Grid<4> {
+  static constexpr int kLevels = 4;
+  static constexpr uint32_t kEntries = 1u << 12;
+  static constexpr float kBand = 0x1.0p-12f;
+  typedef uint32_t Entry;                             // value << 5 | levels << 2 | code
+  static TDT_DEV bool encode(uint32_t v, uint32_t m, uint32_t code, Entry &e) { e = (v << 5) | (m << 2) | code; return true; }
+  static TDT_DEV void decode(uint32_t g, uint32_t &v, uint32_t &m, uint32_t &code) { code = g & 3u; m = (g >> 2) & 7u; v = g >> 5; }
+};
+template <> struct Grid<5> {
+  static constexpr int kLevels = 5;
+  static constexpr uint32_t kEntries = 1u << 15;
+  static constexpr float kBand = 0x1.0p-11f;
+  typedef uint16_t Entry;     // code 1 (PARENT, always after all five levels): value << 2 | 1;  code 0 / 2 (EMPTY / LEAF after `levels` levels): value << 5 | levels << 2 | code, value < 2048
+  static TDT_DEV bool encode(uint32_t v, uint32_t m, uint32_t code, Entry &e) {
+    if (code == 1u) { e = (Entry)((v << 2) | 1u); return v <= kPackedMaxValue && m == 5u; }
+    e = (Entry)((v << 5) | (m << 2) | code);
+    return v < 2048u;
+  }
+  static TDT_DEV void decode(uint32_t g, uint32_t &v, uint32_t &m, uint32_t &code) {
+    code = g & 3u;
+    const bool parent = code == 1u;
+    m = parent ? 5u : (g >> 2) & 7u;
+    v = parent ? g >> 2 : g >> 5;
+  }
+};
+template <int GL>
+TDT_DEV void build_top_grid(const uint16_t *lds, uint32_t lds_nodes, int depth, typename Grid<GL>::Entry *grid, int *grid_ok) {
+  constexpr int kGridLevels = GL;
   if (threadIdx.x == 0) *grid_ok = depth >= kGridLevels ? 1 : 0;
   __syncthreads();
   if (depth >= kGridLevels) {
-    for (uint32_t e = threadIdx.x; e < kGridEntries; e += blockDim.x) {
+    for (uint32_t e = threadIdx.x; e < Grid<GL>::kEntries; e += blockDim.x) {
       const uint32_t xg = e >> (2 * kGridLevels), yg = (e >> kGridLevels) & ((1u << kGridLevels) - 1u), zg = e & ((1u << kGridLevels) - 1u);
       uint32_t v = 0, code = 1u, m = 0;
       bool ok = true;
@@ -304,7 +337,8 @@ TDT_DEV void build_top_grid(const uint16_t *lds, uint32_t lds_nodes, int depth, 
         v = n >> 2; code = n & 3u; m = (uint32_t)l;
         if (code == 1u && l < kGridLevels && v >= grid_v_bound(l)) ok = false;     // this v feeds the next level's x decision
       }
-      grid[e] = (v << 5) | (m << 2) | code;
+      if (code == 1u && m < (uint32_t)kGridLevels) ok = false;     // (the descent was cut short by a table that is unusable anyway)
+      if (!Grid<GL>::encode(v, m, code, grid[e])) ok = false;
       if (!ok) atomicAnd(grid_ok, 0);
     }
   }
@@ -352,14 +386,15 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
   uint32_t qx = 1u, v = 0, code = 1u;                 // qx: x digits below a sentinel bit that counts the levels visited
   const float fx0 = fx;
   bool jumped = false;
+  constexpr int kGridLevels = RESIDENT ? 4 : 5;      // (see Grid<GL>)
   if (!COUNT && DEPTH >= kGridLevels) {              // the top levels in one step (see build_top_grid)
     const float tg = fx0 * (float)(1 << kGridLevels);  // exact
     const bool safe = __builtin_fabsf(tg - __builtin_rintf(tg)) > ns.grid_band;   // (an unusable table has band 2: never safe)
     if (__builtin_expect(__ballot(!safe) == 0ull, 1)) {
       const uint32_t xg = (uint32_t)tg;               // floor: tg in [0, 2^kGridLevels)
-      const uint32_t g = ns.grid[(xg << (2 * kGridLevels)) | ((Yi >> (depth - kGridLevels)) << kGridLevels) | (Zi >> (depth - kGridLevels))];
-      const uint32_t mg = (g >> 2) & 7u;
-      code = g & 3u; v = g >> 5;
+      const uint32_t g = static_cast<const typename Grid<kGridLevels>::Entry *>(ns.grid)[(xg << (2 * kGridLevels)) | ((Yi >> (depth - kGridLevels)) << kGridLevels) | (Zi >> (depth - kGridLevels))];
+      uint32_t mg;
+      Grid<kGridLevels>::decode(g, v, mg, code);
       qx = (1u << mg) | (xg >> ((uint32_t)kGridLevels - mg));
       fx = f_fract_nonneg(tg);                        // fract(c * 2^kGridLevels): the next level's coordinate (only used when code == 1)
       jumped = true;

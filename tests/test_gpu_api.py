@@ -325,5 +325,7 @@ def test_short_rounding_forms_exhaustively():
         assert ctx.selftest(2) == 0      # 1/sqrt(x), two roundings
         assert ctx.selftest(3) > 1000000
         assert ctx.selftest(4) == 0      # v_fract_f32 == x - floor(x) for every x >= 0
-        assert ctx.selftest(5) == 0      # jump table: x decision == binary digit outside the bands, all c in [0,1), all v < 128
+        assert ctx.selftest(5) == 0      # 4-level jump table: x decision == binary digit outside the bands, all c in [0,1), all v below the bounds
         assert ctx.selftest(6) > 0       # ... and not without the bands (harness check)
+        assert ctx.selftest(7) == 0      # the 5-level table of trees that are not LDS-resident (cell indices up to 8191 at level 5)
+        assert ctx.selftest(8) > 0
