@@ -72,7 +72,7 @@ enum : int { ST_TRAVERSE = 0, ST_HIT = 1, ST_END = 2, ST_FETCH = 3, ST_PRIMARY =
 // POW2: exact-comparison treeLookup (see tree_lookup_pow2) vs the literal float form.
 // PROBE changes nothing but the kernel's name: the short probe launch of a two-phase frame (tdt_dispatch_compute) then shows
 // up as its own row in profiler statistics instead of halving the average of the launches that do the work.
-template <bool COUNT, bool POW2, int DEPTH = 0, bool RESIDENT = false, bool SAFEV = false, bool PROBE = false>
+template <bool COUNT, bool POW2, int DEPTH = 0, bool RESIDENT = false, bool SAFEV = false, bool PROBE = false, bool FULL = false>
 __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   __shared__ __attribute__((aligned(16))) uint16_t s_nodes[kLdsCells * 8 + 8];   // + the sentinel slot
   for (uint32_t i = threadIdx.x * 8u; i < P.lds_nodes; i += (uint32_t)TDT_BLOCK * 8u)      // one cell (8 x u16) per lane and trip
@@ -82,14 +82,15 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     s_nodes[P.lds_nodes + threadIdx.x] = (uint16_t)((RESIDENT && POW2) ? 0u : kPackedEscape);
   __syncthreads();
   constexpr int GL = RESIDENT ? 4 : 5;                                 // levels of the top-level jump table (see Grid<GL>)
-  constexpr bool kUseGrid = !COUNT && POW2 && SAFEV && DEPTH >= GL;   // see build_top_grid
+  constexpr bool kUseGrid = !FULL && !COUNT && POW2 && SAFEV && DEPTH >= GL;   // see build_top_grid (FULL: the whole-depth table in global memory instead)
   __shared__ typename Grid<GL>::Entry s_grid[kUseGrid ? Grid<GL>::kEntries : 1];
   __shared__ int s_grid_ok;
   if (kUseGrid) build_top_grid<GL>(s_nodes, P.lds_nodes, DEPTH, s_grid, &s_grid_ok);
   NodeSource ns;
   ns.lds = s_nodes; ns.lds_nodes = P.lds_nodes; ns.lds_cells = (P.lds_nodes + 7u) >> 3;
   ns.grid = s_grid; ns.grid_ok = kUseGrid ? (__builtin_amdgcn_readfirstlane(s_grid_ok) != 0) : false;
-  ns.grid_band = ns.grid_ok ? Grid<GL>::kBand : 2.0f;
+  ns.grid_band = FULL ? Grid<5>::kBand : (ns.grid_ok ? Grid<GL>::kBand : 2.0f);
+  ns.full = P.full_grid;
   ns.cells = __builtin_amdgcn_make_buffer_rsrc((void *)P.cells, 0, (int)((P.cells_dwords >> 1) << 3), 0x00020000);
   const uint32_t total_slots = (uint32_t)P.owned_tiles * 1024u;
 
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       if (inside) {
         float ugx, ugy, ugz; uint32_t value;
         if (COUNT) cnt.iterations++;
-        const bool leaf = POW2 ? tree_lookup_pow2<COUNT, kMemoLevels, DEPTH, RESIDENT, SAFEV>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, memo, cnt)
+        const bool leaf = POW2 ? tree_lookup_pow2<COUNT, kMemoLevels, DEPTH, RESIDENT, SAFEV, FULL>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, memo, cnt)
                                : tree_lookup<COUNT>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, cnt);
         lane_work += kCostStep + (127u - (__float_as_uint(inv_pow_depth) >> 23));   // + tree levels visited (inv_pow_depth = 2^-levels)
         const float bx = ugx * P.scale + P.min_x, by = ugy * P.scale + P.min_y, bz = ugz * P.scale + P.min_z;
@@ -442,6 +443,33 @@ __global__ __launch_bounds__(256) void scan_cells_kernel(const uint32_t *__restr
     mp = a > mp ? a : mp; ma = b > ma ? b : ma;
   }
   if ((threadIdx.x & 63) == 0) { atomicMax(&out[0], mp); atomicMax(&out[1], ma); }
+}
+
+// The whole-depth table of FULL builds (see tree_lookup_pow2): entry (x, y, z digits of a finest-level voxel position) = what
+// treeLookup's descent with those child digits ends on.  16 bits: PARENT (only the last level can hold one): value << 2 | 1;
+// EMPTY / LEAF after `levels` levels: value << 5 | levels << 2 | code.  *bad is raised when the tree does not fit the claim the
+// table rests on (a PARENT of a level that feeds a later x decision at or above grid_v_bound) or an entry does not fit 16 bits.
+__global__ __launch_bounds__(256) void build_full_grid_kernel(const uint32_t *__restrict__ cells, uint32_t cells_dwords, int depth,
+                                                             uint16_t *__restrict__ grid, uint32_t *__restrict__ bad) {
+  const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+  if (e >= (1u << (3 * depth))) return;
+  const uint32_t xg = e >> (2 * depth), yg = (e >> depth) & ((1u << depth) - 1u), zg = e & ((1u << depth) - 1u);
+  uint32_t v = 0, code = 1u, m = 0;
+  bool ok = true;
+  for (int l = 1; l <= depth && code == 1u; l++) {
+    const int sh = depth - l;
+    const uint32_t idx = ((2u * v + ((xg >> sh) & 1u)) << 2) + (((yg >> sh) & 1u) << 1) + ((zg >> sh) & 1u);
+    uint32_t value = 0, type = 0;
+    if (2u * idx + 1u < cells_dwords) { value = cells[2u * idx]; type = cells[2u * idx + 1u]; }     // reads past the end are 0 (robust access)
+    code = (type == 0u) ? 0u : (type == 2u ? 2u : 1u);
+    v = value; m = (uint32_t)l;
+    if (code == 1u && l < depth && v >= grid_v_bound(l)) ok = false;
+  }
+  uint32_t enc;
+  if (code == 1u) { enc = (v << 2) | 1u; ok = ok && v <= 0x3FFFu; }
+  else { enc = (v << 5) | (m << 2) | code; ok = ok && v < 2048u; }
+  grid[e] = (uint16_t)enc;
+  if (!ok) atomicOr(bad, 1u);
 }
 
 // Exhaustive check of the short correctly-rounded forms against the IEEE expressions: every one of
@@ -868,10 +896,34 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     const bool resident = buf_nodes == P.lds_nodes && buf_nodes > 0 && (P.cells_dwords & 1u) == 0 && ctx->max_any_value <= tdt::kPackedMaxValue;
     bool launched = false;
     P.accumulate = mode == 1 ? 1 : 0;
+    // small resident trees: the whole-depth lookup table (tree_lookup_pow2 FULL), built once per cells buffer
+    bool full = false;
+    if (mode != 2 && !counts_out && pow2 && safev && resident && !ctx->no_specialise && !ctx->no_full && (P.max_depth == 5 || P.max_depth == 6)) {
+      const tdt_buffer *cb = ctx->ssbo[TDT_SLOT_CELLS];
+      if (ctx->full_of != cb || ctx->full_version != cb->version || ctx->full_depth != P.max_depth) {
+        const size_t entries = (size_t)1 << (3 * P.max_depth);
+        if (!ctx->full_grid) TDT_HIP(ctx, hipMalloc((void **)&ctx->full_grid, ((size_t)1 << 18) * sizeof(uint16_t) + sizeof(uint32_t)));
+        uint32_t *bad = reinterpret_cast<uint32_t *>(ctx->full_grid + ((size_t)1 << 18));
+        TDT_HIP(ctx, hipMemsetAsync(bad, 0, sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(tdt::build_full_grid_kernel, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, ctx->stream, P.cells, P.cells_dwords, P.max_depth, ctx->full_grid, bad);
+        TDT_HIP(ctx, hipGetLastError());
+        uint32_t flag = 1;
+        TDT_HIP(ctx, hipMemcpyAsync(&flag, bad, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
+        TDT_HIP(ctx, hipStreamSynchronize(ctx->stream));    // once per cells buffer (version), not per frame
+        ctx->full_of = cb; ctx->full_version = cb->version; ctx->full_depth = P.max_depth; ctx->full_ok = flag == 0;
+      }
+      full = ctx->full_ok;
+      P.full_grid = ctx->full_grid;
+    }
     if (mode != 2 && !counts_out && pow2 && safev && !ctx->no_specialise) {
 #define TDT_SPEC(D, R) if (ctx->probe_launch) hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, R, true, true>), grid, block, 0, ctx->stream, P); \
                        else hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, R, true>), grid, block, 0, ctx->stream, P); \
                        launched = true; break
+#define TDT_SPEC_FULL(D) if (ctx->probe_launch) hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, true, true, true, true>), grid, block, 0, ctx->stream, P); \
+                         else hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, true, true, false, true>), grid, block, 0, ctx->stream, P); \
+                         launched = true; break
+      if (full) switch (P.max_depth) { case 5: TDT_SPEC_FULL(5); case 6: TDT_SPEC_FULL(6); default: break; }
+      else
       if (resident) switch (P.max_depth) {
         case 3: TDT_SPEC(3, true); case 4: TDT_SPEC(4, true); case 5: TDT_SPEC(5, true); case 6: TDT_SPEC(6, true);
         case 7: TDT_SPEC(7, true); default: break; }
@@ -879,6 +931,7 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
         case 6: TDT_SPEC(6, false); case 7: TDT_SPEC(7, false); case 8: TDT_SPEC(8, false); case 9: TDT_SPEC(9, false);
         case 10: TDT_SPEC(10, false); default: break; }
 #undef TDT_SPEC
+#undef TDT_SPEC_FULL
     }
 #define TDT_LAUNCH(C) do { if (pow2) hipLaunchKernelGGL((tdt::trace_kernel<C, true>), grid, block, 0, ctx->stream, P); \
                            else hipLaunchKernelGGL((tdt::trace_kernel<C, false>), grid, block, 0, ctx->stream, P); } while (0)
@@ -941,6 +994,7 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
     const char *fs = getenv("TDT_ORDER_SMOOTH"); ctx->force_smooth = fs ? atoi(fs) : -1;
     ctx->no_cost_accum = getenv("TDT_NO_COST_ACCUM") != nullptr;
     ctx->no_two_phase = getenv("TDT_NO_TWO_PHASE") != nullptr;
+    ctx->no_full = getenv("TDT_NO_FULL_GRID") != nullptr;
     const char *ms = getenv("TDT_MAX_SHARE"); ctx->max_share = ms ? (float)atof(ms) : 0.25f;
     const char *ob = getenv("TDT_ORDER_BLEND"); ctx->order_blend = ob ? (float)atof(ob) : 0.5f; }
   ctx->scan = nullptr; ctx->max_parent_value = ctx->max_any_value = 0xFFFFFFFFu;
@@ -978,6 +1032,7 @@ void tdt_ctx_destroy(tdt_ctx *ctx) {
   if (ctx->pixel_log) (void)hipFree(ctx->pixel_log);
   if (ctx->present) (void)hipFree(ctx->present);
   if (ctx->frame_carry) (void)hipFree(ctx->frame_carry);
+  if (ctx->full_grid) (void)hipFree(ctx->full_grid);
   if (ctx->phase_timing) for (auto &e : ctx->phase_ev) (void)hipEventDestroy(e);
   tdt::edit_scratch_destroy(ctx);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

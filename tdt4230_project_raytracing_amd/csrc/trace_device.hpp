@@ -157,6 +157,7 @@ struct NodeSource {
   uint32_t lds_cells;                                 // cells they make up (the last may be partial): index of the sentinel cell
   const void *grid;                                   // top-level jump table (Grid<GL>::Entry[], see build_top_grid), or unusable when !grid_ok
   bool grid_ok; float grid_band;                      // grid_band = kGridBand, or 2 when the table is unusable
+  const uint16_t *full;                               // FULL builds: the whole-depth table in global memory (see tree_lookup_pow2)
   __amdgpu_buffer_rsrc_t cells;                       // raw buffer over the cells payload (8-byte granules)
 };
 
@@ -371,7 +372,12 @@ constexpr int kMemoFirst = 3;       // levels 1..3 = cells 0..72 at most: always
 //   RESIDENT    : the whole cells buffer sits in the LDS table and no node needed the escape code
 //   SAFEV       : every PARENT value in the buffer is < 2^22 (scanned once per buffer), so the
 //                 literal-formula branch for huge cell indices cannot be taken
-template <bool COUNT, int CL, int DEPTH, bool RESIDENT, bool SAFEV>
+// FULL (round 2; small trees: max_depth 5 or 6, wholly LDS-resident): the jump table idea taken to the last level — one 16-bit
+// entry per finest-level voxel position (8^depth of them: 64 KB / 512 KB, built once per cells buffer by build_full_grid_kernel,
+// read through L2) holds what the whole descent ends on, so a traversal step does ONE load instead of a table read plus two
+// more levels; the bands are those of the 5-level table (cell indices of a resident tree stay below 8192: 2^-11 around the
+// integers of 2^depth c), and a wave with a lane inside one walks all levels from the LDS node table.
+template <bool COUNT, int CL, int DEPTH, bool RESIDENT, bool SAFEV, bool FULL = false>
 TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float fx, float fy, float fz, float &inv_pow_depth,
                               float &gx, float &gy, float &gz, uint32_t &value, NodeMemo<CL> &memo, Counters &cnt) {
   const int depth = DEPTH > 0 ? DEPTH : P.max_depth;
@@ -386,15 +392,29 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
   uint32_t qx = 1u, v = 0, code = 1u;                 // qx: x digits below a sentinel bit that counts the levels visited
   const float fx0 = fx;
   bool jumped = false;
-  constexpr int kGridLevels = RESIDENT ? 4 : 5;      // (see Grid<GL>)
-  if (!COUNT && DEPTH >= kGridLevels) {              // the top levels in one step (see build_top_grid)
+  constexpr int kTableLevels = RESIDENT ? 4 : 5;                      // (see Grid<GL>)
+  constexpr int kGridLevels = FULL ? DEPTH : kTableLevels;            // levels the jump covers
+  if constexpr (FULL && !COUNT) {
+    const float tg = fx0 * (float)(1 << DEPTH);       // exact
+    const bool safe = __builtin_fabsf(tg - __builtin_rintf(tg)) > ns.grid_band;
+    if (__builtin_expect(__ballot(!safe) == 0ull, 1)) {
+      const uint32_t xg = (uint32_t)tg;
+      const uint32_t g = ns.full[(xg << (2 * DEPTH)) | (Yi << DEPTH) | Zi];
+      code = g & 3u;
+      const bool parent = code == 1u;                 // (a PARENT can only be what the last level holds)
+      const uint32_t mg = parent ? (uint32_t)DEPTH : (g >> 2) & 7u;
+      v = parent ? g >> 2 : g >> 5;
+      qx = (1u << mg) | (xg >> ((uint32_t)DEPTH - mg));
+      jumped = true;
+    }
+  } else if constexpr (!COUNT && DEPTH >= kTableLevels) {        // the top levels in one step (see build_top_grid)
     const float tg = fx0 * (float)(1 << kGridLevels);  // exact
     const bool safe = __builtin_fabsf(tg - __builtin_rintf(tg)) > ns.grid_band;   // (an unusable table has band 2: never safe)
     if (__builtin_expect(__ballot(!safe) == 0ull, 1)) {
       const uint32_t xg = (uint32_t)tg;               // floor: tg in [0, 2^kGridLevels)
-      const uint32_t g = static_cast<const typename Grid<kGridLevels>::Entry *>(ns.grid)[(xg << (2 * kGridLevels)) | ((Yi >> (depth - kGridLevels)) << kGridLevels) | (Zi >> (depth - kGridLevels))];
+      const uint32_t g = static_cast<const typename Grid<kTableLevels>::Entry *>(ns.grid)[(xg << (2 * kGridLevels)) | ((Yi >> (depth - kGridLevels)) << kGridLevels) | (Zi >> (depth - kGridLevels))];
       uint32_t mg;
-      Grid<kGridLevels>::decode(g, v, mg, code);
+      Grid<kTableLevels>::decode(g, v, mg, code);
       qx = (1u << mg) | (xg >> ((uint32_t)kGridLevels - mg));
       fx = f_fract_nonneg(tg);                        // fract(c * 2^kGridLevels): the next level's coordinate (only used when code == 1)
       jumped = true;
