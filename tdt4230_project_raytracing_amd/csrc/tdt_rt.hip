@@ -128,7 +128,8 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   // per issue slot peak at  T = 64 / (1/2 + sqrt(r n)),  r = C_t / (2 C_e);  n is measured per wave over a
   // sliding window of kEventWindow rays (in cost order a wave meets the expensive pixels first and the sky
   // last).  r (P.event_k) is fitted: 0.2 while the tree fits one XCD's L2, rising to 0.5 beyond — there the
-  // node loads' latency, not issue slots, bounds a traversal pass and event passes come almost free.
+  // node loads' latency, not issue slots, bounds a traversal pass and event passes come almost free.  (Round 2, after the
+  // traversal step had become cheaper: 0.12 ... 0.35.)
   uint32_t w_steps = 0, w_rays = 0, lane_work = 0;
   int threshold = P.event_threshold > 0 ? P.event_threshold : 24;
 
@@ -774,10 +775,11 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
                    "bound image is neither camera.image_width x image_height nor a 32 x 32*tiles tile buffer");
   P.spp_begin = spp_begin; P.spp_count = spp_count; P.mode = mode; P.total_spp = total_spp;
   P.event_threshold = ctx->event_threshold;   // 0: adaptive (see trace_kernel)
-  {  // r of the adaptive event threshold (see trace_kernel): 0.2 up to 2 MiB of cells, 0.5 from 5 MiB on
+  {  // r of the adaptive event threshold (see trace_kernel): 0.12 up to 1.7 MiB of cells, 0.35 from 5 MiB on (refitted in round 2:
+     // the traversal step lost a fifth of its instructions, which moves the optimum towards fewer, fuller event passes)
     const float mib = (float)ctx->ssbo[TDT_SLOT_CELLS]->bytes / 1048576.0f;
-    const float r = 0.1f * mib;
-    P.event_k = ctx->event_k > 0.0f ? ctx->event_k : (r < 0.2f ? 0.2f : (r > 0.5f ? 0.5f : r));
+    const float r = 0.07f * mib;
+    P.event_k = ctx->event_k > 0.0f ? ctx->event_k : (r < 0.12f ? 0.12f : (r > 0.35f ? 0.35f : r));
   }
 
   TDT_HIP(ctx, hipSetDevice(ctx->device));
