@@ -464,7 +464,7 @@ def main():
                 c = torch.zeros((IH, IW, 16), dtype=torch.float32, device=R.dev)
                 wl.full.zero_()
             R.stream.synchronize()
-            r.shader.dispatch_accumulate(dw, dh, 1, 0, probe, c.data_ptr())
+            r.shader.dispatch_counted_range(dw, dh, 1, 0, probe, c.data_ptr())      # (instrumented too: keeps the product kernel's profile rows to whole launches)
             counts_main = r.shader.dispatch_counted_range(dw, dh, 1, probe, spp - probe, c.data_ptr())
             main_read, _ = algorithmic_bytes(counts_main)
             kernel_ms, kernel_note = phase[1], f"main launch of the two-phase frame: samples [{probe}, {spp}) of every pixel in the cost order of this frame's probe"
