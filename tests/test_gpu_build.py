@@ -66,7 +66,7 @@ def test_random_ragged_models(ctx, seed):
     assert_same_payloads(ctx, host.Ply(ply_bytes(xyz, rgb)), max_iter=50, z_up=bool(seed & 2))
 
 
-@pytest.mark.parametrize("cfg", [1, 2])
+@pytest.mark.parametrize("cfg", [1, 2, 3])
 def test_synthetic_scene_cells(ctx, cfg):
     scene = host.Scene.config(cfg)
     vox = expand_cells(scene.blobs[0], scene.max_depth)

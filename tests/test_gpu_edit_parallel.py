@@ -5,60 +5,10 @@ import numpy as np
 import pytest
 
 import oracle_py
+from octree_util import distinct_deltas, edit_setup as setup
 from tdt4230_project_raytracing_amd import host, rt
 
 pytestmark = pytest.mark.gpu
-
-
-def setup(scene, counter0, delta_floats):
-    cam = host.camera_reference_pose(64, 64, 1, 2)
-    r = rt.Renderer(scene, cam)
-    upd = rt.ComputeShader(r.ctx, rt.PROGRAM_OCTREE_UPDATE)
-    counter = rt.VertexBufferObject(r.ctx, np.array([counter0], np.uint32))
-    r.ctx.bind_buffer_base(rt.ATOMIC_COUNTER_BUFFER, 0, counter)
-    dv = rt.VertexBufferObject(r.ctx, np.ascontiguousarray(delta_floats, np.float32))
-    r.ctx.bind_buffer_base(rt.SHADER_STORAGE_BUFFER, 5, dv)
-    return r, upd, counter
-
-
-def written_node(cells, p, depth):
-    """Index of the node of the tree AS IT IS that an edit at p (strictly inside a finest-level cell, so treeLookupLeaf's
-    float index arithmetic is plain binary digits) writes first: its first EMPTY node, or the last node of a full walk."""
-    g = 1 << depth
-    q = [int(c * g) for c in p]
-    value, index = 0, 0
-    for level in range(1, depth):                        # max_depth - 1 levels (octree_update.comp:63)
-        sh = depth - level
-        index = (((2 * value + ((q[0] >> sh) & 1)) << 1) + ((q[1] >> sh) & 1) << 1) + ((q[2] >> sh) & 1)
-        if cells[2 * index + 1] == 0:
-            return index
-        if cells[2 * index + 1] == 2 and level < depth - 1:
-            return None                                  # a LEAF above the last level: the shader follows its material index as
-        value = int(cells[2 * index])                    # if it were a cell index, into the top of the tree — a real collision
-    return index
-
-
-def distinct_deltas(rng, n, depth, cells=None):
-    """Up to n edits, each in its own cell of the level the walk ends on, and — when `cells` is given — no two of them
-    writing the same node of the tree as it is (two edits under one EMPTY node both want to turn it into a PARENT)."""
-    g = 1 << (depth - 1)
-    idx = rng.permutation(g ** 3)[: (n if cells is None else 60 * n)]
-    p = np.stack([idx // (g * g), (idx // g) % g, idx % g], 1).astype(np.float32)
-    pos = (p + rng.uniform(0.3, 0.7, size=p.shape).astype(np.float32)) / np.float32(g)
-    if cells is not None:
-        seen, keep = set(), []
-        for i, q in enumerate(pos):
-            w = written_node(cells, q, depth)
-            if w is not None and w not in seen:
-                seen.add(w); keep.append(i)
-                if len(keep) == n:
-                    break
-        pos = pos[keep]
-    d = np.zeros((len(pos), 8), np.float32)
-    d[:, :3] = pos
-    d[:, 3] = rng.integers(0, 3, size=len(pos))
-    d[:, 4] = rng.integers(0, 12, size=len(pos))
-    return d
 
 
 @pytest.mark.parametrize("cfg,n", [(2, 1000), (3, 4096), (1, 40)])
