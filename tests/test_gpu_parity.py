@@ -97,3 +97,27 @@ def test_relocated_top_cells_disable_the_jump_table(oracle):
             assert (got.view(np.uint32) == ref.view(np.uint32)).all()
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("cfg,scale", [(2, 2.0), (2, 0.75), (3, 2.0), (1, 3.0)])
+def test_octree_scale_other_than_one(oracle, cfg, scale):
+    """Octree::new takes any scale (main.rs:455-463 passes 1.0, and the kernels have builds that skip the multiplications by an
+    exact 1.0f): a scene moved and scaled in world space, the camera moved and scaled with it — the builds that DO multiply,
+    against the oracle (resident whole-depth table, 5-level table and small-tree forms)."""
+    scene = host.Scene.config(cfg)
+    of = scene.blobs[6].copy()
+    s = np.float32(scale)
+    of[0:3] = np.array([-0.5, -0.5, -1.0], np.float32) * s + np.array([0.25, -0.125, 0.5], np.float32)
+    of[4] = s
+    of[5] = np.float32(1.0) / s                                        # octree.rs:47: inv_scale = 1.0 / scale
+    scene.blobs[6] = of
+    cam = host.camera_build(90.0, 200, aspect_ratio=200 / 120, viewport_height=2.0,
+                            origin=(float(0.0 * s + 0.25), float(-0.1 * s - 0.125), float(-0.3 * s + 0.5)), samples_per_pixel=16, max_bounce=6)
+    ref = oracle.render(scene, cam, threads=8)
+    r = rt.Renderer(scene, cam)
+    try:
+        first, again = r.render(), r.render()
+    finally:
+        r.close()
+    assert _bits_equal(first, ref).all() and _bits_equal(again, ref).all()
+    assert (ref[..., :3] != ref[0, 0, :3]).any()                       # the scene is in view
