@@ -57,6 +57,7 @@ struct tdt_ctx {
   uint32_t *slot_cost, *slot_acc, *slot_order, *order_hist;   // per queue slot: cost feedback of the last trace dispatch, the hand-out order derived from it; 2 x 256 sort counters
   uint32_t cost_dispatches;            // dispatches summed into slot_cost so far
   uint32_t acc_samples, last_launch_samples;   // samples per pixel behind slot_acc / traced by the last launch
+  int probe_div;                       // TDT_PROBE_DIV: probe samples of a two-phase frame = spp / probe_div (16)
   float order_blend;                   // TDT_ORDER_BLEND: weight of the 8x8-tile mean in a thin (probe) cost estimate
   uint32_t tile_capacity, cost_tiles;  // allocation size (work-groups); number of work-groups slot_cost holds the last dispatch's costs for (0: none)
   CostSig cost_sig;                    // what those costs were measured on (camera, octree parameters, buffer versions, partition)

@@ -1001,7 +1001,8 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
     ctx->no_two_phase = getenv("TDT_NO_TWO_PHASE") != nullptr;
     ctx->no_full = getenv("TDT_NO_FULL_GRID") != nullptr;
     const char *ms = getenv("TDT_MAX_SHARE"); ctx->max_share = ms ? (float)atof(ms) : 0.25f;
-    const char *ob = getenv("TDT_ORDER_BLEND"); ctx->order_blend = ob ? (float)atof(ob) : 0.5f; }
+    const char *ob = getenv("TDT_ORDER_BLEND"); ctx->order_blend = ob ? (float)atof(ob) : 0.5f;
+    const char *pd = getenv("TDT_PROBE_DIV"); ctx->probe_div = pd && atoi(pd) >= 2 && atoi(pd) <= 64 ? atoi(pd) : 16; }
   ctx->scan = nullptr; ctx->max_parent_value = ctx->max_any_value = 0xFFFFFFFFu;
   { hipDeviceProp_t prop; ctx->num_cus = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
   { const char *fg = getenv("TDT_FORCE_GENERIC"); ctx->force_generic = fg && fg[0] == '1';
@@ -1326,7 +1327,7 @@ int tdt_dispatch_compute(tdt_compute *c, int width, int height, int depth) {
   // same bits as one pass (tests/test_gpu_fullsize.py).  Frames that repeat their inputs take one pass in the exact order.
   tdt_ctx *ctx = c->ctx;
   const int spp = c->samples_per_pixel;
-  bool ready = ctx->image0 != nullptr && !ctx->no_cost_order && !ctx->no_two_phase && spp >= 16;
+  bool ready = ctx->image0 != nullptr && !ctx->no_cost_order && !ctx->no_two_phase && spp >= 16 && spp / ctx->probe_div >= 1;
   for (int sl : {TDT_SLOT_CELLS, TDT_SLOT_MATERIALS, TDT_SLOT_ALBEDOS, TDT_SLOT_METAL, TDT_SLOT_DIELECTRIC, TDT_SLOT_OCTREE_FLOATS, TDT_SLOT_OCTREE_INTS})
     ready = ready && ctx->ssbo[sl] != nullptr;
   if (ready && ctx->ssbo[TDT_SLOT_OCTREE_FLOATS]->bytes >= 28 && ctx->ssbo[TDT_SLOT_OCTREE_INTS]->bytes >= 12) {
@@ -1345,7 +1346,7 @@ int tdt_dispatch_compute(tdt_compute *c, int width, int height, int depth) {
         TDT_HIP(ctx, hipMalloc(&ctx->frame_carry, need));
         ctx->frame_carry_bytes = need;
       }
-      const int probe = spp / 16;                    // measured: 1/8 and 1/32 are 0-3 % slower, 1/64 5 %
+      const int probe = spp / ctx->probe_div;        // spp/16; measured: 1/8 and 1/32 are 0-3 % slower, 1/64 5 % (TDT_PROBE_DIV)
       ctx->probe_launch = true;
       phase_mark(ctx, 0);
       int rc = launch(c, width, height, depth, 1, 0, probe, ctx->frame_carry, 0, nullptr);
