@@ -253,7 +253,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
         float4 *dst = reinterpret_cast<float4 *>(P.image) + pix;
         if (P.accumulate) {
           *dst = make_float4(sr, sg, sb, 0.f);
-          if (P.carry) {
+          if (P.carry && !P.carry_final) {           // (the last launch of a two-phase frame: nobody will read the records again)
             float4 *c = reinterpret_cast<float4 *>(P.carry) + pix * 4;
             c[0] = make_float4(pc.root.nx, pc.root.ny, pc.root.nz, pc.root.px);
             c[1] = make_float4(pc.root.py, pc.root.pz, pc.root.ff ? 1.f : 0.f, pc.root_t);
@@ -766,7 +766,7 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
   P.albedos = (const uint32_t *)ctx->ssbo[TDT_SLOT_ALBEDOS]->dev; P.albedos_dwords = dwords(ctx->ssbo[TDT_SLOT_ALBEDOS]);
   P.metal = (const uint32_t *)ctx->ssbo[TDT_SLOT_METAL]->dev; P.metal_dwords = dwords(ctx->ssbo[TDT_SLOT_METAL]);
   P.dielectric = (const uint32_t *)ctx->ssbo[TDT_SLOT_DIELECTRIC]->dev; P.dielectric_dwords = dwords(ctx->ssbo[TDT_SLOT_DIELECTRIC]);
-  P.image = img->dev; P.carry = (float *)carry;
+  P.image = img->dev; P.carry = (float *)carry; P.carry_final = ctx->carry_final ? 1 : 0;
   Cover k = cover_of(c, width, height);
   Tiles t = tiles_of(c, k);
   P.cover_w = k.cover_w; P.cover_h = k.cover_h;
@@ -1352,7 +1352,9 @@ int tdt_dispatch_compute(tdt_compute *c, int width, int height, int depth) {
       int rc = launch(c, width, height, depth, 1, 0, probe, ctx->frame_carry, 0, nullptr);
       ctx->probe_launch = false;
       phase_mark(ctx, 1);
+      ctx->carry_final = true;                       // 64 B per pixel that the resolve does not read: not written
       if (rc == TDT_OK) rc = launch(c, width, height, depth, 1, probe, spp - probe, ctx->frame_carry, 0, nullptr);
+      ctx->carry_final = false;
       phase_mark(ctx, 2);
       if (rc == TDT_OK) rc = launch(c, width, height, depth, 2, 0, 0, nullptr, spp, nullptr);
       phase_mark(ctx, 3);

@@ -35,6 +35,7 @@ struct TraceParams {
   int32_t part_rank, part_world;  // work-group partition: tile t (row-major) belongs to rank t % world
   int32_t spp_begin, spp_count;   // sample range of this launch
   const uint32_t *plan;           // device word written by order_plan_kernel: 1 = draw queue slots exactly as asked, 0 / null = in batches of 64
+  int32_t carry_final;            // 1: read the records in `carry` at the start of a pixel but do not store them at its end
   int32_t accumulate;             // 0: main() as written (resolve and store); 1: add the samples to the running sums in `image`
   int32_t mode;                // 0 render (sum, sqrt, clamp, store), 1 accumulate into image, 2 resolve
   int32_t total_spp;           // resolve divisor
