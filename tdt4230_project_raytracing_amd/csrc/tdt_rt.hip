@@ -108,7 +108,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   int x = 0, y = 0; size_t pix = 0;
   uint32_t pixel_slot = 0;                          // queue slot (work-group * 1024 + pixel) of the current pixel
   const bool exact_draw = P.plan != nullptr && __builtin_amdgcn_readfirstlane((int)P.plan[0]) != 0;
-  uint32_t buf_slot = 0xFFFFFFFFu, buf_next = 0u, buf_count = 0u, buf_base = 0u;   // the wave's batch of queue slots: lane i holds the i-th; dealt / size / where it started
+  uint32_t buf_slot = 0xFFFFFFFFu, buf_next = 0u, buf_count = 0u;   // the wave's batch of queue slots: lane i holds the i-th; dealt / size
   int s = 0, loop_count = 0;
   Ray r = {0.f, 0.f, 0.f, 0.f, 0.f, 1.f};
   float ix = 0.f, iy = 0.f, iz = 0.f;                // 1 / direction (ray-invariant, rc:319)
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
           base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
           const uint32_t bq = base + (threadIdx.x & 63u);
           buf_slot = ((threadIdx.x & 63u) < chunk && bq < total_slots) ? (P.slot_order ? P.slot_order[bq] : bq) : 0xFFFFFFFFu;
-          buf_next = 0u; buf_count = chunk; buf_base = base;
+          buf_next = 0u; buf_count = chunk;
           if (COUNT && base + chunk > total_slots) wave_drained = true;
         }
         const uint32_t rank = (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
