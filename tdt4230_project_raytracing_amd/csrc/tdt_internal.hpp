@@ -71,7 +71,6 @@ struct tdt_ctx {
   float event_k;        // TDT_EVENT_K overrides the adaptive threshold's r (0: chosen from the tree size)
   void *frame_carry; size_t frame_carry_bytes;   // hit-record carry between the two phases of a frame (tdt_dispatch_compute)
   bool no_two_phase;                             // TDT_NO_TWO_PHASE=1
-  bool wavefront; float *wf_pc;                  // TDT_WAVEFRONT=1 (experiment): the wavefront form of the FULL builds and its per-context records
   uint16_t *full_grid; const tdt_buffer *full_of; unsigned long long full_version; int full_depth; bool full_ok, no_full;   // whole-depth lookup table of small resident trees (TDT_NO_FULL_GRID=1: off)
   bool carry_final;                              // set around the last launch of a two-phase frame: its records need not be stored
   bool probe_launch;                             // set around the probe launch of a two-phase frame (kernel name only)

@@ -408,8 +408,6 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   }
 }
 
-#include "trace_wavefront.hpp"
-
 __global__ __launch_bounds__(256) void resolve_kernel(const TraceParams P) {
   int x, y; size_t pix;
   if (!pixel_of_thread(P, x, y, pix)) return;
@@ -928,19 +926,7 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
                               else hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, R, true, false, F, U>), grid, block, 0, ctx->stream, P)
 #define TDT_SPEC(D, R) if (unit) TDT_SPEC4(D, R, false, true); else TDT_SPEC4(D, R, false, false); launched = true; break
 #define TDT_SPEC_FULL(D) if (unit) TDT_SPEC4(D, true, true, true); else TDT_SPEC4(D, true, true, false); launched = true; break
-      // EXPERIMENT (TDT_WAVEFRONT=1): the wavefront form of the FULL builds (trace_wavefront.hpp)
-      if (full && ctx->wavefront && (P.materials_dwords / 3u) <= 1024u && P.spp_begin + P.spp_count < 65536) {
-        if (!ctx->wf_pc) TDT_HIP(ctx, hipMalloc((void **)&ctx->wf_pc, (size_t)ctx->num_cus * tdt::kWfPcWords * tdt::kWfContexts * sizeof(float)));
-        P.wf_pc = ctx->wf_pc;
-#define TDT_WF(D) if (unit) { if (ctx->probe_launch) hipLaunchKernelGGL((tdt::trace_wf_kernel<D, true, true>), grid, block, 0, ctx->stream, P); \
-                              else hipLaunchKernelGGL((tdt::trace_wf_kernel<D, true, false>), grid, block, 0, ctx->stream, P); } \
-                  else { if (ctx->probe_launch) hipLaunchKernelGGL((tdt::trace_wf_kernel<D, false, true>), grid, block, 0, ctx->stream, P); \
-                         else hipLaunchKernelGGL((tdt::trace_wf_kernel<D, false, false>), grid, block, 0, ctx->stream, P); } \
-                  launched = true; break
-        switch (P.max_depth) { case 5: TDT_WF(5); case 6: TDT_WF(6); default: break; }
-#undef TDT_WF
-      }
-      else if (full) switch (P.max_depth) { case 5: TDT_SPEC_FULL(5); case 6: TDT_SPEC_FULL(6); default: break; }
+      if (full) switch (P.max_depth) { case 5: TDT_SPEC_FULL(5); case 6: TDT_SPEC_FULL(6); default: break; }
       else
       if (resident) switch (P.max_depth) {
         case 3: TDT_SPEC(3, true); case 4: TDT_SPEC(4, true); case 5: TDT_SPEC(5, true); case 6: TDT_SPEC(6, true);
@@ -1014,7 +1000,6 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
     ctx->no_cost_accum = getenv("TDT_NO_COST_ACCUM") != nullptr;
     ctx->no_two_phase = getenv("TDT_NO_TWO_PHASE") != nullptr;
     ctx->no_full = getenv("TDT_NO_FULL_GRID") != nullptr;
-    ctx->wavefront = getenv("TDT_WAVEFRONT") != nullptr;
     const char *ms = getenv("TDT_MAX_SHARE"); ctx->max_share = ms ? (float)atof(ms) : 0.25f;
     const char *ob = getenv("TDT_ORDER_BLEND"); ctx->order_blend = ob ? (float)atof(ob) : 0.5f;
     const char *pd = getenv("TDT_PROBE_DIV"); ctx->probe_div = pd && atoi(pd) >= 2 && atoi(pd) <= 64 ? atoi(pd) : 16; }
@@ -1054,7 +1039,6 @@ void tdt_ctx_destroy(tdt_ctx *ctx) {
   if (ctx->present) (void)hipFree(ctx->present);
   if (ctx->frame_carry) (void)hipFree(ctx->frame_carry);
   if (ctx->full_grid) (void)hipFree(ctx->full_grid);
-  if (ctx->wf_pc) (void)hipFree(ctx->wf_pc);
   if (ctx->phase_timing) for (auto &e : ctx->phase_ev) (void)hipEventDestroy(e);
   tdt::edit_scratch_destroy(ctx);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

@@ -27,7 +27,6 @@ struct TraceParams {
   uint32_t *slot_cost;          // per queue slot: pixel time of THIS dispatch (feeds the next one), or null
   const uint16_t *packed;       // cells [0, lds_cells) re-encoded as 16 bits per node: value << 2 | code
   uint32_t lds_nodes;           // number of nodes (8 per cell) staged in LDS by every block
-  float *wf_pc;                 // wavefront form: per block [16 words][1280 contexts] of hit records (trace_wavefront.hpp)
   const uint16_t *full_grid;    // FULL builds: one entry per finest-level voxel position (8^max_depth), see build_full_grid_kernel
   int32_t compact;             // 1: image is this rank's tile buffer [owned tile k][32][32] RGBA
   int32_t cover_w, cover_h;    // pixels a dispatch covers: min(32*groups, image size)
