@@ -246,8 +246,13 @@ int tdt_debug_pixel_log(tdt_ctx *ctx, uint32_t *out, size_t n_u32);
  * rsq (2) forms against the IEEE expressions, of v_fract_f32 against x - floor(x) for x >= 0 (4), and of the top-level
  * jump tables' claim (5: the 4-level table of LDS-resident trees, 7: the 5-level table of the others): for every coordinate
  * in [0,1) outside the table's bands and every cell index below its bounds (128 / 1024 / 8192 by level) the x decision of
- * treeLookup's first four / five levels is the coordinate's binary digit.  *mismatches must be 0.  Modes 3, 6 and 8 check
- * the harness: the raw reciprocal seed, and the claims without the bands, must fail. */
+ * treeLookup's first four / five levels is the coordinate's binary digit; and of the short form of CubeHit's normal (9: every
+ * bit pattern of the dominant component x zeros / smaller values / ties / NaN on the other axes x ray directions with zero,
+ * denormal, inf and NaN components: where its guard holds it returns the bits of the literal normalise-orient-normalise
+ * sequence); and of the two one-parameter divisions taken through reciprocal + residual step (11: pow's (m - 1) / (m + 1) for
+ * every mantissa, reflectance's (1 - x) / (1 + x) for every x).  *mismatches must be 0.  Modes 3, 6, 8, 10 and 12 check the
+ * harness: the raw reciprocal seed, the claims without the bands, the short normal without its guard, and the divisions
+ * without the residual step, must fail. */
 int tdt_selftest(tdt_ctx *ctx, int which, uint64_t *mismatches);
 
 #ifdef __cplusplus

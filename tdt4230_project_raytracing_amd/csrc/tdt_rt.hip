@@ -507,6 +507,46 @@ __global__ __launch_bounds__(256) void selftest_kernel(int which, unsigned long 
       }
       continue;
     }
+    if (which == 9 || which == 10) {
+      // cube_normal_fast's claim: wherever cube_normal_fast_ok holds, it returns the bits of the literal sequence.  x is the
+      // component on axis k; the two others run over zeros, smaller values, ties and non-finite values; the ray direction
+      // over the sign combinations and zero / denormal / inf / NaN components.  10 checks the harness: without the guard the
+      // claim must fail (ties, NaNs, the ends of the exponent range).
+      const float nan = __uint_as_float(0x7FC00000u), inf = __builtin_inff();
+      const float others[8][2] = {{0.f, 0.f}, {-0.f, 0.f}, {0.5f * x, -0.25f * x}, {-0.75f * x, 0.f}, {x, 0.f}, {0.f, -x}, {1e-30f, -1e-30f}, {nan, 0.f}};
+      const float dirs[12][3] = {{1.f, 1.f, 1.f}, {-1.f, 1.f, 1.f}, {1.f, -1.f, 1.f}, {1.f, 1.f, -1.f}, {-0.3f, -0.5f, -0.8f}, {0.6f, -0.0f, 0.8f}, {0.f, 0.f, 1.f},
+                                 {0.f, -1.f, 0.f}, {1e-40f, -1e-40f, 1.f}, {inf, 1.f, -1.f}, {1.f, nan, 1.f}, {-0.f, 0.f, -0.f}};
+      for (int k = 0; k < 3; k++) for (int o = 0; o < 8; o++) for (int d = 0; d < 12; d++) {
+        const float u = others[o][0], w = others[o][1];
+        const float nx = k == 0 ? x : u, ny = k == 1 ? x : (k == 0 ? u : w), nz = k == 2 ? x : w;
+        const Ray r = {0.f, 0.f, 0.f, dirs[d][0], dirs[d][1], dirs[d][2]};
+        bool sx, sy, sz;
+        const bool ok = cube_normal_fast_ok(nx, ny, nz, sx, sy, sz);
+        if (!ok && which == 9) continue;
+        HitTmp f, l;
+        cube_normal_fast(r, nx, ny, nz, sx, sy, sz, f);
+        cube_normal_literal(r, nx, ny, nz, l);
+        const bool same = (__float_as_uint(f.nx) == __float_as_uint(l.nx) || (f.nx != f.nx && l.nx != l.nx)) &&
+                          (__float_as_uint(f.ny) == __float_as_uint(l.ny) || (f.ny != f.ny && l.ny != l.ny)) &&
+                          (__float_as_uint(f.nz) == __float_as_uint(l.nz) || (f.nz != f.nz && l.nz != l.nz)) && f.ff == l.ff;
+        bad += same ? 0u : 1u;
+      }
+      continue;
+    }
+    if (which == 11 || which == 12) {
+      // the two one-parameter divisions done as reciprocal + residual step (div_core): pow_poly's (m - 1) / (m + 1) for every
+      // mantissa, and reflectance's (1 - x) / (1 + x) for every x whose operands lie in the window.  12: the harness — without
+      // the residual step the quotients must differ somewhere.
+      const float m = __uint_as_float((i & 0x007FFFFFu) | 0x3F800000u);
+      const float n1 = m - 1.0f, d1 = m + 1.0f, n2 = 1.0f + -x, d2 = 1.0f + x;
+      const float s1 = which == 11 ? div_core(n1, d1) : n1 * rcp_core(d1), l1 = n1 / d1;
+      bad += (__float_as_uint(s1) == __float_as_uint(l1)) ? 0u : 1u;
+      if (exp_in_window(n2) && exp_in_window(d2)) {
+        const float s2 = which == 11 ? div_core(n2, d2) : n2 * rcp_core(d2), l2 = n2 / d2;
+        bad += (__float_as_uint(s2) == __float_as_uint(l2)) ? 0u : 1u;
+      }
+      continue;
+    }
     float a, b;
     if (which == 0) { a = q_rcp(x); b = 1.0f / x; }
     else if (which == 1) { a = q_sqrt(x); b = __builtin_sqrtf(x); }
@@ -1477,7 +1517,7 @@ int tdt_debug_wave_ends(tdt_ctx *ctx, uint64_t *out, int n) {
 /* Exhaustive self-test of the kernels' short correctly-rounded rcp / sqrt / rsq forms against the
  * IEEE expressions on all 2^32 inputs; *mismatches must come back 0 (which: 0 rcp, 1 sqrt, 2 rsq). */
 int tdt_selftest(tdt_ctx *ctx, int which, uint64_t *mismatches) {
-  if (!ctx || !mismatches || which < 0 || which > 8) return TDT_ERR_INVALID_VALUE;
+  if (!ctx || !mismatches || which < 0 || which > 12) return TDT_ERR_INVALID_VALUE;
   TDT_HIP(ctx, hipSetDevice(ctx->device));
   if (!ctx->counters) TDT_HIP(ctx, hipMalloc((void **)&ctx->counters, (32 + 16384 + 256) * sizeof(unsigned long long)));
   TDT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));

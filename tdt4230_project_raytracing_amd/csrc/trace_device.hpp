@@ -62,6 +62,28 @@ TDT_DEV float q_rsq(float x) {             // RN(1 / RN(sqrt(x))): sqrt of a win
   if (__builtin_expect(__ballot(!pos_in_window(x)) != 0ull, 0)) return 1.0f / __builtin_sqrtf(x);
   return rcp_core(sqrt_core(x));
 }
+// a / b through the correctly rounded reciprocal and one residual step.  NOT claimed for all operand pairs: used at two call sites
+// whose operands are functions of ONE float, and checked there for every bit pattern of it (tdt_selftest mode 11).
+TDT_DEV float div_core(float a, float b) {
+  const float r = rcp_core(b), q0 = a * r;
+  return __builtin_fmaf(__builtin_fmaf(-b, q0, a), r, q0);
+}
+// (m - 1) / (m + 1) for a mantissa m in [1, 2): pow_poly's log2 argument (operands always in the window)
+TDT_DEV float pow_t(float m) {
+#ifdef TDT_LITERAL_NORMAL
+  return (m - 1.0f) / (m + 1.0f);
+#else
+  return div_core(m - 1.0f, m + 1.0f);
+#endif
+}
+// (1 - x) / (1 + x): reflectance's r0 before squaring (rc:495), x = the refraction ratio
+TDT_DEV float schlick_q(float x) {
+  const float a = 1.0f + -x, b = 1.0f + x;
+#ifndef TDT_LITERAL_NORMAL
+  if (__builtin_expect(__ballot(!(exp_in_window(a) && exp_in_window(b))) == 0ull, 1)) return div_core(a, b);
+#endif
+  return a / b;
+}
 // min/max where a NaN operand yields the other operand (and ties return b)
 TDT_DEV float f_min(float a, float b) { return (b != b) ? a : (a < b ? a : b); }
 TDT_DEV float f_max(float a, float b) { return (b != b) ? a : (a > b ? a : b); }
@@ -112,7 +134,7 @@ TDT_DEV float pow_poly(float x, float yy) {
   uint32_t u = __float_as_uint(x);
   float e = (float)((int32_t)((u >> 23) & 0xff) - 127);
   float m = __uint_as_float((u & 0x007fffffu) | 0x3f800000u);
-  float t = (m - 1.0f) / (m + 1.0f);
+  float t = pow_t(m);
   float z = t * t;
   float z2 = z * z;
   float even = __builtin_fmaf(z2, __builtin_fmaf(z2, 0.406718052498846252698f, 0.577440339438736392009f), 2.88539009343309178325f);
@@ -196,11 +218,9 @@ struct HitTmp { float nx, ny, nz, px, py, pz; bool ff; };
 struct Carry { HitTmp root; float root_t; HitTmp leaf; };
 struct Hit { float px, py, pz, nx, ny, nz; bool ff; uint32_t index; };
 
-// CubeHit's record for entry parameter t (rc:336-354)
-TDT_DEV void cube_hit_record(const Ray &r, float t, float cx, float cy, float cz, float size, HitTmp &h) {
-  float px = t * r.dx + r.ox, py = t * r.dy + r.oy, pz = t * r.dz + r.oz;
-  float radius = size * 0.5f;
-  float nx = px + -(cx + radius), ny = py + -(cy + radius), nz = pz + -(cz + radius);
+// The normal and the front-face flag of CubeHit's record (rc:341-353) from q = p - centre, as the shader computes them: mask all
+// but the dominant axis, normalise, orient against the ray, normalise again.
+TDT_DEV void cube_normal_literal(const Ray &r, float nx, float ny, float nz, HitTmp &h) {
   float ax = __builtin_fabsf(nx), ay = __builtin_fabsf(ny), az = __builtin_fabsf(nz);
   nx = nx * b2f(ax >= f_max(ay, az));
   ny = ny * b2f(f_max(ax, az) < ay);
@@ -212,7 +232,44 @@ TDT_DEV void cube_hit_record(const Ray &r, float t, float cx, float cy, float cz
   nx = nx * flip; ny = ny * flip; nz = nz * flip;
   rs = q_rsq((nz * nz + ny * ny) + nx * nx);
   h.nx = nx * rs; h.ny = ny * rs; h.nz = nz * rs;
-  h.ff = ff; h.px = px; h.py = py; h.pz = pz;
+  h.ff = ff;
+}
+// What that sequence yields when exactly one axis is selected and its |v| is far from the ends of the exponent range (the
+// others are finite): sqrt(RN(v^2)) is |v| in binary floating point, g(x) = RN(x * RN(1/x)) is 1 or 1 - 2^-24, and g(g(x)) = 1
+// — so the selected component ends as +-1.0 and the masked ones as zeros that keep q's sign, all flipped for a back face;
+// the front-face test only looks at the sign of d_k * n_k, which +-1.0 has in common with the once-normalised value.  Two
+// reciprocal square roots and 14 multiplications less, per record (two records per bounce).  Checked against the literal
+// form for every bit pattern of the selected component x a grid of the other operands (tdt_selftest mode 9); anything else
+// (ties between axes — an edge hit selects no axis and yields NaNs —, NaN / inf / out-of-window operands) takes the literal form.
+TDT_DEV bool cube_normal_fast_ok(float nx, float ny, float nz, bool &sx, bool &sy, bool &sz) {
+  const float ax = __builtin_fabsf(nx), ay = __builtin_fabsf(ny), az = __builtin_fabsf(nz);
+  sx = ax >= hw_max(ay, az); sy = hw_max(ax, az) < ay; sz = hw_max(ax, ay) < az;     // (NaN operands fail the window test below)
+  const float sum = (ax + ay) + az;                    // max <= sum <= 3 max; NaN and inf propagate
+  return (sx || sy || sz) && (__float_as_uint(sum) - 0x27000000u) < (0x58000000u - 0x27000000u);      // 2^-49 <= sum < 2^49
+}
+TDT_DEV void cube_normal_fast(const Ray &r, float nx, float ny, float nz, bool sx, bool sy, bool sz, HitTmp &h) {
+  const uint32_t ex = (__float_as_uint(nx) & 0x80000000u) | (sx ? 0x3F800000u : 0u);
+  const uint32_t ey = (__float_as_uint(ny) & 0x80000000u) | (sy ? 0x3F800000u : 0u);
+  const uint32_t ez = (__float_as_uint(nz) & 0x80000000u) | (sz ? 0x3F800000u : 0u);
+  const bool ff = (r.dz * __uint_as_float(ez) + r.dy * __uint_as_float(ey)) < -(r.dx * __uint_as_float(ex));
+  const uint32_t fl = ff ? 0u : 0x80000000u;
+  h.nx = __uint_as_float(ex ^ fl); h.ny = __uint_as_float(ey ^ fl); h.nz = __uint_as_float(ez ^ fl);
+  h.ff = ff;
+}
+// CubeHit's record for entry parameter t (rc:336-354)
+TDT_DEV void cube_hit_record(const Ray &r, float t, float cx, float cy, float cz, float size, HitTmp &h) {
+  float px = t * r.dx + r.ox, py = t * r.dy + r.oy, pz = t * r.dz + r.oz;
+  float radius = size * 0.5f;
+  float nx = px + -(cx + radius), ny = py + -(cy + radius), nz = pz + -(cz + radius);
+  h.px = px; h.py = py; h.pz = pz;
+#ifdef TDT_LITERAL_NORMAL                               // (A/B builds)
+  cube_normal_literal(r, nx, ny, nz, h);
+#else
+  bool sx, sy, sz;
+  const bool ok = cube_normal_fast_ok(nx, ny, nz, sx, sy, sz);
+  if (__builtin_expect(__ballot(!ok) != 0ull, 0)) cube_normal_literal(r, nx, ny, nz, h);
+  else cube_normal_fast(r, nx, ny, nz, sx, sy, sz, h);
+#endif
 }
 
 // slab test rc:317-331 (t_min / t_max in the first operand slot of the min/max chain)
@@ -532,6 +589,18 @@ TDT_DEV MatRef material_fetch(const TraceParams &P, uint32_t index) {
   return m;
 }
 
+// normalize(n) of a hit record's normal (rc:471, rc:485).  CubeHit's normals are +-1 on one axis and zeros on the others
+// (cube_normal_fast), so the squared length is exactly 1.0f, 1 / sqrt(1.0f) is 1.0f and n * 1.0f is n: nothing to do.  Whatever
+// else a record may hold (the zeros of a pixel's first, never-written record; NaNs) takes the arithmetic.
+TDT_DEV void unit_or_normalised(float nx, float ny, float nz, float &mx, float &my, float &mz) {
+  const float nn = (nz * nz + ny * ny) + nx * nx;
+#ifndef TDT_LITERAL_NORMAL
+  if (__builtin_expect(__ballot(nn != 1.0f) == 0ull, 1)) { mx = nx; my = ny; mz = nz; return; }
+#endif
+  const float rs = q_rsq(nn);
+  mx = nx * rs; my = ny * rs; mz = nz * rs;
+}
+
 // switch (materials[hit.index].type) rc:278-291; returns false when the path ends
 template <bool COUNT>
 TDT_DEV bool scatter(const TraceParams &P, const Ray &r, const Hit &h, const MatRef &mat, Ray &out, float &ar, float &ag, float &ab, Counters &cnt) {
@@ -545,8 +614,8 @@ TDT_DEV bool scatter(const TraceParams &P, const Ray &r, const Hit &h, const Mat
   if (type == 0) {   // ScatterLambertian rc:470-482, constructFrisvad rc:453-468, SampleGGXVNDF rc:27-49
     const float alb_r = __uint_as_float(ld_dw(P.albedos, P.albedos_dwords, ai)), alb_g = __uint_as_float(ld_dw(P.albedos, P.albedos_dwords, ai + 4u)),
                 alb_b = __uint_as_float(ld_dw(P.albedos, P.albedos_dwords, ai + 8u));
-    float rs = q_rsq((nz * nz + ny * ny) + nx * nx);
-    float mx = nx * rs, my = ny * rs, mz = nz * rs;
+    float mx, my, mz; float rs;
+    unit_or_normalised(nx, ny, nz, mx, my, mz);
     bool sing = nz < -0.9999f;
     float a = q_rcp(1.0f + nz);
     float b = -((nx * ny) * a);
@@ -604,8 +673,8 @@ TDT_DEV bool scatter(const TraceParams &P, const Ray &r, const Hit &h, const Mat
     const float alb_r = __uint_as_float(ld_dw(P.albedos, P.albedos_dwords, ai)), alb_g = __uint_as_float(ld_dw(P.albedos, P.albedos_dwords, ai + 4u)),
                 alb_b = __uint_as_float(ld_dw(P.albedos, P.albedos_dwords, ai + 8u));
     const float m_fuzz = __uint_as_float(ld_dw(P.metal, P.metal_dwords, mat.attribute << 2));
-    float rs = q_rsq((nz * nz + ny * ny) + nx * nx);
-    float mx = nx * rs, my = ny * rs, mz = nz * rs;
+    float mx, my, mz; float rs;
+    unit_or_normalised(nx, ny, nz, mx, my, mz);
     float dt = ((mz * dz + my * dy) + mx * dx) * 2.0f;
     float rx = dx + -(dt * mx), ry = dy + -(dt * my), rz = dz + -(dt * mz);
     const float fuzz = m_fuzz;
@@ -628,7 +697,7 @@ TDT_DEV bool scatter(const TraceParams &P, const Ray &r, const Hit &h, const Mat
     float cos_t = f_min((-pz_ + -py_) + -px_, 1.0f);
     float sin_t = q_sqrt(1.0f + -(cos_t * cos_t));
     bool cannot = 1.0f < ratio * sin_t;
-    float q = (1.0f + -ratio) / (1.0f + ratio);
+    float q = schlick_q(ratio);
     float r0 = q * q;
     float rnd = rand2(h.px, h.py);
     float refl = pow_poly(1.0f + -cos_t, 5.0f) * (1.0f + -r0) + r0;

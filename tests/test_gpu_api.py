@@ -329,3 +329,7 @@ def test_short_rounding_forms_exhaustively():
         assert ctx.selftest(6) > 0       # ... and not without the bands (harness check)
         assert ctx.selftest(7) == 0      # the 5-level table of trees that are not LDS-resident (cell indices up to 8191 at level 5)
         assert ctx.selftest(8) > 0
+        assert ctx.selftest(9) == 0      # CubeHit's normal: +-1 / signed zeros where the guard holds == the literal normalise-orient-normalise
+        assert ctx.selftest(10) > 0      # ... and not without the guard
+        assert ctx.selftest(11) == 0     # (m-1)/(m+1) and (1-x)/(1+x) through reciprocal + residual step == IEEE division
+        assert ctx.selftest(12) > 0
