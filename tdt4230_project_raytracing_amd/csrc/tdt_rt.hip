@@ -450,9 +450,10 @@ __global__ __launch_bounds__(256) void scan_cells_kernel(const uint32_t *__restr
 }
 
 // The whole-depth table of FULL builds (see tree_lookup_pow2): entry (x, y, z digits of a finest-level voxel position) = what
-// treeLookup's descent with those child digits ends on.  16 bits: PARENT (only the last level can hold one): value << 2 | 1;
-// EMPTY / LEAF after `levels` levels: value << 5 | levels << 2 | code.  *bad is raised when the tree does not fit the claim the
-// table rests on (a PARENT of a level that feeds a later x decision at or above grid_v_bound) or an entry does not fit 16 bits.
+// treeLookup's descent with those child digits ends on.  16 bits: levels << 2 | code, and for a LEAF its value << 5 (the only
+// value a traversal step uses; a PARENT can only be what the last level holds).  *bad is raised when the tree does not fit the
+// claim the table rests on (a PARENT of a level that feeds a later x decision at or above grid_v_bound) or a material index
+// does not fit 11 bits.
 __global__ __launch_bounds__(256) void build_full_grid_kernel(const uint32_t *__restrict__ cells, uint32_t cells_dwords, int depth,
                                                              uint16_t *__restrict__ grid, uint32_t *__restrict__ bad) {
   const uint32_t e = blockIdx.x * 256u + threadIdx.x;
@@ -469,9 +470,8 @@ __global__ __launch_bounds__(256) void build_full_grid_kernel(const uint32_t *__
     v = value; m = (uint32_t)l;
     if (code == 1u && l < depth && v >= grid_v_bound(l)) ok = false;
   }
-  uint32_t enc;
-  if (code == 1u) { enc = (v << 2) | 1u; ok = ok && v <= 0x3FFFu; }
-  else { enc = (v << 5) | (m << 2) | code; ok = ok && v < 2048u; }
+  uint32_t enc = (m << 2) | code;                      // (a PARENT: m = depth)
+  if (code == 2u) { enc |= v << 5; ok = ok && v < 2048u; }
   grid[e] = (uint16_t)enc;
   if (!ok) atomicOr(bad, 1u);
 }

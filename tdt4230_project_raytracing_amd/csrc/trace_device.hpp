@@ -455,14 +455,15 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
     const float tg = fx0 * (float)(1 << DEPTH);       // exact
     const bool safe = __builtin_fabsf(tg - __builtin_rintf(tg)) > ns.grid_band;
     if (__builtin_expect(__ballot(!safe) == 0ull, 1)) {
+      // the whole lookup: levels visited, the cell's digits and what it holds (see build_full_grid_kernel)
       const uint32_t xg = (uint32_t)tg;
       const uint32_t g = ns.full[(xg << (2 * DEPTH)) | (Yi << DEPTH) | Zi];
-      code = g & 3u;
-      const bool parent = code == 1u;                 // (a PARENT can only be what the last level holds)
-      const uint32_t mg = parent ? (uint32_t)DEPTH : (g >> 2) & 7u;
-      v = parent ? g >> 2 : g >> 5;
-      qx = (1u << mg) | (xg >> ((uint32_t)DEPTH - mg));
-      jumped = true;
+      const uint32_t mg = (g >> 2) & 7u, sh = (uint32_t)DEPTH - mg;
+      const float ipd = __uint_as_float((127u - mg) << 23);                   // 2^-levels
+      gx = (float)(xg >> sh) * ipd; gy = (float)(Yi >> sh) * ipd; gz = (float)(Zi >> sh) * ipd;
+      inv_pow_depth = ipd;
+      value = g >> 5;
+      return (g & 3u) == 2u;
     }
   } else if constexpr (!COUNT && DEPTH >= kTableLevels) {        // the top levels in one step (see build_top_grid)
     const float tg = fx0 * (float)(1 << kGridLevels);  // exact
