@@ -548,15 +548,20 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
     }
     fx = f_fract_nonneg(fx0 * __uint_as_float((uint32_t)(127 + l) << 23));   // fract(c * 2^l): next level's coordinate
   };
-  if (!jumped) {
+  constexpr int kFirstAfterJump = (kGridLevels > kMemoFirst ? kGridLevels : kMemoFirst) + 1;
+  if (!jumped) {                                      // (wave-uniform) the levels a jump would have covered
 #pragma unroll
     for (int l = 1; l <= kMemoFirst; l++) {
       if (code == 1u && l <= depth) level(l, nullptr, nullptr);
     }
+#pragma unroll
+    for (int l = kMemoFirst + 1; l < kFirstAfterJump; l++) {
+      if (code == 1u && l <= depth) level(l, &memo.key[l - kMemoFirst - 1], &memo.val[l - kMemoFirst - 1]);
+    }
   }
 #pragma unroll
-  for (int l = kMemoFirst + 1; l <= kMemoFirst + CL; l++) {
-    if (code == 1u && l <= depth && !(jumped && l <= kGridLevels)) level(l, &memo.key[l - kMemoFirst - 1], &memo.val[l - kMemoFirst - 1]);
+  for (int l = kFirstAfterJump; l <= kMemoFirst + CL; l++) {
+    if (code == 1u && l <= depth) level(l, &memo.key[l - kMemoFirst - 1], &memo.val[l - kMemoFirst - 1]);
   }
   for (int l = kMemoFirst + CL + 1; code == 1u && l <= depth; l++) level(l, nullptr, nullptr);
   const int m = 31 - __builtin_clz(qx);               // levels visited
