@@ -92,6 +92,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   ns.grid_band = FULL ? Grid<5>::kBand : (ns.grid_ok ? Grid<GL>::kBand : 2.0f);
   ns.full = P.full_grid;
   ns.cells = __builtin_amdgcn_make_buffer_rsrc((void *)P.cells, 0, (int)((P.cells_dwords >> 1) << 3), 0x00020000);
+  const MatSource ms = material_source(P);
   const uint32_t total_slots = (uint32_t)P.owned_tiles * 1024u;
 
   const float inf = __builtin_inff();
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     if (COUNT) lane_E += (state != ST_TRAVERSE && state != ST_DONE) ? 1u : 0u;
     if (state == ST_HIT) {                            // RayColor loop body rc:272-295
       if (COUNT) { cnt.scatter_slots += slot64(); cnt.scatter_active++; }
-      const MatRef mat = material_fetch(P, hit_index);
+      const MatRef mat = material_fetch(ms, hit_index);
       if (leaf_rec) { cube_hit_record(r, t_stride, leaf_box_x, leaf_box_y, leaf_box_z, inv_pow_depth, pc.leaf); if (COUNT) cnt.leaf_records++; }
       loop_count += 1;
       const HitTmp &src = use_leaf ? pc.leaf : pc.root;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       h.px = src.px; h.py = src.py; h.pz = src.pz; h.nx = src.nx; h.ny = src.ny; h.nz = src.nz; h.ff = src.ff;
       h.index = hit_index;
       Ray nr; float tr, tg, tb;
-      if (scatter<COUNT>(P, r, h, mat, nr, tr, tg, tb, cnt)) {
+      if (scatter<COUNT>(ms, r, h, mat, nr, tr, tg, tb, cnt)) {
         ar = ar * tr; ag = ag * tg; ab = ab * tb;
         r = nr;
         // rc:271: the bounce limit ends the path here and now — ST_END is handled further down in this same pass; going
@@ -818,11 +819,11 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
                    "bound image is neither camera.image_width x image_height nor a 32 x 32*tiles tile buffer");
   P.spp_begin = spp_begin; P.spp_count = spp_count; P.mode = mode; P.total_spp = total_spp;
   P.event_threshold = ctx->event_threshold;   // 0: adaptive (see trace_kernel)
-  {  // r of the adaptive event threshold (see trace_kernel): 0.12 up to 1.7 MiB of cells, 0.35 from 5 MiB on (refitted in round 2:
+  {  // r of the adaptive event threshold (see trace_kernel): 0.10 up to 1.4 MiB of cells, 0.35 from 5 MiB on (refitted twice in round 2:
      // the traversal step lost a fifth of its instructions, which moves the optimum towards fewer, fuller event passes)
     const float mib = (float)ctx->ssbo[TDT_SLOT_CELLS]->bytes / 1048576.0f;
     const float r = 0.07f * mib;
-    P.event_k = ctx->event_k > 0.0f ? ctx->event_k : (r < 0.12f ? 0.12f : (r > 0.35f ? 0.35f : r));
+    P.event_k = ctx->event_k > 0.0f ? ctx->event_k : (r < 0.10f ? 0.10f : (r > 0.35f ? 0.35f : r));
   }
 
   TDT_HIP(ctx, hipSetDevice(ctx->device));

@@ -583,15 +583,30 @@ TDT_DEV float rand2(float cx, float cy) {   // Rand(vec2) rc:53
   return f_fract(sin_poly(cy * 78.233f + cx * 12.9898f) * 43758.5453f);
 }
 
-// materials[hit.index] (rc:189-196): the three dwords are fetched together, and as early as the hit is known, so that the
-// round trip overlaps the hit record's arithmetic instead of standing in front of the material switch
+// The material tables (rc:189-222) behind raw buffer descriptors: the hardware's range check returns 0 for a dword past the end,
+// which IS the reference's robust-access rule, and — unlike a compare-and-branch per load — leaves the loads free to overlap:
+// one round trip for materials[hit.index]'s three dwords, one more for everything they point at (albedo, fuzz, index of
+// refraction: all issued, whatever the type turns out to be; a table the material does not use is read and ignored).
+struct MatSource { __amdgpu_buffer_rsrc_t materials, albedos, metal, dielectric; };
+TDT_DEV __amdgpu_buffer_rsrc_t table_rsrc(const uint32_t *p, uint32_t dwords) {      // (a 32-bit byte offset cannot reach past 2^30 dwords)
+  return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)(dwords < (1u << 30) ? dwords << 2 : 0xFFFFFFFFu), 0x00020000);
+}
+TDT_DEV MatSource material_source(const TraceParams &P) {
+  MatSource ms;
+  ms.materials = table_rsrc(P.materials, P.materials_dwords); ms.albedos = table_rsrc(P.albedos, P.albedos_dwords);
+  ms.metal = table_rsrc(P.metal, P.metal_dwords); ms.dielectric = table_rsrc(P.dielectric, P.dielectric_dwords);
+  return ms;
+}
+TDT_DEV uint32_t ld_buf(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off) { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)byte_off, 0, 0); }
+// materials[hit.index] (rc:189-196): fetched as early as the hit is known, so that the round trip overlaps the hit record's
+// arithmetic instead of standing in front of the material switch
 struct MatRef { uint32_t type, attribute, albedo; };
-TDT_DEV MatRef material_fetch(const TraceParams &P, uint32_t index) {
+TDT_DEV MatRef material_fetch(const MatSource &ms, uint32_t index) {
   const uint32_t mo = index * 12u;
   MatRef m;
-  m.type = ld_dw(P.materials, P.materials_dwords, mo);
-  m.attribute = ld_dw(P.materials, P.materials_dwords, mo + 4u);
-  m.albedo = ld_dw(P.materials, P.materials_dwords, mo + 8u);
+  m.type = ld_buf(ms.materials, mo);
+  m.attribute = ld_buf(ms.materials, mo + 4u);
+  m.albedo = ld_buf(ms.materials, mo + 8u);
   return m;
 }
 
@@ -609,17 +624,17 @@ TDT_DEV void unit_or_normalised(float nx, float ny, float nz, float &mx, float &
 
 // switch (materials[hit.index].type) rc:278-291; returns false when the path ends
 template <bool COUNT>
-TDT_DEV bool scatter(const TraceParams &P, const Ray &r, const Hit &h, const MatRef &mat, Ray &out, float &ar, float &ag, float &ab, Counters &cnt) {
+TDT_DEV bool scatter(const MatSource &ms, const Ray &r, const Hit &h, const MatRef &mat, Ray &out, float &ar, float &ag, float &ab, Counters &cnt) {
   const int32_t type = (int32_t)mat.type;
-  // the second-level reads (albedo; fuzz or index of refraction) are issued at the top of each branch and used at its end
-  const uint32_t ai = mat.albedo * 12u;
+  // the second-level reads, all of them, before the switch (see MatSource); used at the end of the branches
+  const uint32_t ai = mat.albedo * 12u, at = mat.attribute << 2;
+  const float alb_r = __uint_as_float(ld_buf(ms.albedos, ai)), alb_g = __uint_as_float(ld_buf(ms.albedos, ai + 4u)), alb_b = __uint_as_float(ld_buf(ms.albedos, ai + 8u));
+  const float m_fuzz = __uint_as_float(ld_buf(ms.metal, at)), ir = __uint_as_float(ld_buf(ms.dielectric, at));
   float dx = r.dx, dy = r.dy, dz = r.dz;
   float nx = h.nx, ny = h.ny, nz = h.nz;
   out.ox = h.px; out.oy = h.py; out.oz = h.pz;
   if (COUNT) { cnt.lambertian += (type == 0); cnt.metal += (type == 1); cnt.dielectric += (type == 2); cnt.unknown += ((uint32_t)type > 2u); }
   if (type == 0) {   // ScatterLambertian rc:470-482, constructFrisvad rc:453-468, SampleGGXVNDF rc:27-49
-    const float alb_r = __uint_as_float(ld_dw(P.albedos, P.albedos_dwords, ai)), alb_g = __uint_as_float(ld_dw(P.albedos, P.albedos_dwords, ai + 4u)),
-                alb_b = __uint_as_float(ld_dw(P.albedos, P.albedos_dwords, ai + 8u));
     float mx, my, mz; float rs;
     unit_or_normalised(nx, ny, nz, mx, my, mz);
     bool sing = nz < -0.9999f;
@@ -676,9 +691,6 @@ TDT_DEV bool scatter(const TraceParams &P, const Ray &r, const Hit &h, const Mat
     return true;
   }
   if (type == 1) {   // ScatterMetal rc:484-491, RandInHemisphere rc:106-115 (one cube sample, as compiled)
-    const float alb_r = __uint_as_float(ld_dw(P.albedos, P.albedos_dwords, ai)), alb_g = __uint_as_float(ld_dw(P.albedos, P.albedos_dwords, ai + 4u)),
-                alb_b = __uint_as_float(ld_dw(P.albedos, P.albedos_dwords, ai + 8u));
-    const float m_fuzz = __uint_as_float(ld_dw(P.metal, P.metal_dwords, mat.attribute << 2));
     float mx, my, mz; float rs;
     unit_or_normalised(nx, ny, nz, mx, my, mz);
     float dt = ((mz * dz + my * dy) + mx * dx) * 2.0f;
@@ -697,7 +709,6 @@ TDT_DEV bool scatter(const TraceParams &P, const Ray &r, const Hit &h, const Mat
     return -(qz * nz + qy * ny) < qx * nx;
   }
   if (type == 2) {   // ScatterDielectric rc:499-522, reflectance rc:494-497
-    const float ir = __uint_as_float(ld_dw(P.dielectric, P.dielectric_dwords, mat.attribute << 2));
     float ratio = h.ff ? q_rcp(ir) : ir;
     float pz_ = dz * nz, py_ = dy * ny, px_ = dx * nx;
     float cos_t = f_min((-pz_ + -py_) + -px_, 1.0f);
