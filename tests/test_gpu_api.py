@@ -316,6 +316,26 @@ def test_out_of_range_cells_read_as_empty(oracle):
     assert _eq(got, oracle.render(scene, cam, threads=4))
 
 
+@pytest.mark.parametrize("slot,keep_bytes", [(1, 12 * 2 + 4), (1, 12 * 1 + 8), (1, 12), (2, 12 * 2 + 4), (2, 8), (3, 4), (3, 0), (4, 4), (4, 0)])
+def test_out_of_range_material_tables_read_as_zero(oracle, slot, keep_bytes):
+    """Robust buffer access on the material tables (dword by dword, as llvmpipe checks them): a materials / albedos /
+    metal / dielectric buffer cut inside a record, or down to nothing, must give what the oracle's zero reads give."""
+    scene = host.Scene.generate(host.SCENE_TERRAIN, 5, 1 << 14, 100, 0x5EED0011)
+    m = scene.blobs[1].reshape(-1, 3).copy()             # every record non-zero in every dword: a record cut in two must not read as all zeros
+    m[:, 0] = 1 + (np.arange(len(m)) % 2); m[:, 1] = 1 + (np.arange(len(m)) % 3); m[:, 2] = 1 + (np.arange(len(m)) % 5)
+    scene.blobs[1] = m.reshape(-1)
+    keep = max(keep_bytes, 4) if keep_bytes else 4       # (a zero-size buffer cannot be created: one dword of zeros reads the same)
+    blob = np.frombuffer(scene.blobs[slot].tobytes()[:keep_bytes].ljust(keep, b"\0"), dtype=np.uint32).copy()
+    scene.blobs[slot] = blob
+    cam = host.camera_reference_pose(96, 64, 2, 6)
+    r = rt.Renderer(scene, cam)
+    try:
+        got = r.render()
+    finally:
+        r.close()
+    assert _eq(got, oracle.render(scene, cam, threads=4))
+
+
 def test_short_rounding_forms_exhaustively():
     """The kernels' 3/5-instruction rcp / sqrt / rsq equal the IEEE expressions on ALL 2^32 inputs
     (and the harness does detect an inexact form: the raw hardware reciprocal seed fails)."""
