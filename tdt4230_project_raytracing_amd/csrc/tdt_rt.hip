@@ -653,10 +653,14 @@ __global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restric
 }
 
 // How the next dispatch draws slots from the queue (see the fetch code of trace_kernel): plan[0] = 1 -> exactly as asked,
-// 0 -> in batches of 64.  Batches make a wave's 64 pixels alike (4K/256^3: -9 %) and spare most queue round trips, but a
-// slot parked in a batch starts late, which costs more than it gains once single pixels are long against the frame
-// (1080p/512^3, where a pixel can take 40 % of the frame: +4 %).  From the cost histogram: f = c_hi * lanes / sum(cost) is the
-// share of the frame a pixel of the 99.9th cost percentile occupies its lane for; exact drawing when f > max_share.
+// 0 -> in batches of 64.  Batches make a wave's 64 pixels alike (4K/256^3: -9 %) and spare most queue round trips — an exact
+// draw stalls the wave for an atomic and a dependent read of the hand-out order every time ONE lane finishes a pixel — but a
+// slot parked in a batch starts late, which must cost more than it gains once a single pixel is long against the frame.  From
+// the cost histogram: f = c_hi * lanes / sum(cost) is the share of the frame a pixel of the 99.9th cost percentile occupies its
+// lane for; exact drawing when f > max_share = 1 (such a pixel alone outlasts the average lane's whole frame).  Round 1 had
+// drawn the line at 0.25, between the 4K/256^3 and the 1080p/512^3 frames it was fitted on; re-measured in round 2 on the
+// three bench frames, batches win or tie on all of them (1080p/64^3, f = 0.3: 24.8 -> 20.9 ms history-free; 1080p/512^3:
+// 158 -> 155 ms history-free, 125.7 -> 126.9 replay), and no frame in the repository reaches f = 1.
 __global__ __launch_bounds__(512) void order_plan_kernel(const uint32_t *__restrict__ hist, uint32_t g, uint32_t lanes, float max_share,
                                                          uint32_t *__restrict__ plan) {
   __shared__ float s_sum[512];
@@ -1041,7 +1045,7 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
     ctx->no_cost_accum = getenv("TDT_NO_COST_ACCUM") != nullptr;
     ctx->no_two_phase = getenv("TDT_NO_TWO_PHASE") != nullptr;
     ctx->no_full = getenv("TDT_NO_FULL_GRID") != nullptr;
-    const char *ms = getenv("TDT_MAX_SHARE"); ctx->max_share = ms ? (float)atof(ms) : 0.25f;
+    const char *ms = getenv("TDT_MAX_SHARE"); ctx->max_share = ms ? (float)atof(ms) : 1.0f;
     const char *ob = getenv("TDT_ORDER_BLEND"); ctx->order_blend = ob ? (float)atof(ob) : 0.5f;
     const char *pd = getenv("TDT_PROBE_DIV"); ctx->probe_div = pd && atoi(pd) >= 2 && atoi(pd) <= 64 ? atoi(pd) : 16; }
   ctx->scan = nullptr; ctx->max_parent_value = ctx->max_any_value = 0xFFFFFFFFu;
