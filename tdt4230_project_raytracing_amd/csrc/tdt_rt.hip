@@ -37,7 +37,9 @@ namespace tdt {
 // built from the previous dispatch's per-pixel work counts ("Cost-feedback scheduling" below).
 TDT_DEV void decode_pixel(const TraceParams &P, int k, uint32_t p, int &x, int &y, size_t &pix, bool &inside) {
   const int t = P.part_rank + k * P.part_world;
-  const int gx = t % P.tiles_x, gy = t / P.tiles_x;
+  int gx, gy;
+  if (P.tiles_x_magic) { gy = (int)__umulhi((uint32_t)t, P.tiles_x_magic); gx = t - gy * P.tiles_x; }      // (uniform; see TraceParams)
+  else { gx = t % P.tiles_x; gy = t / P.tiles_x; }
   const int tile = (int)(p >> 6), w = (int)(p & 63);
   const int lx = (tile & 3) * 8 + (w & 7), ly = (tile >> 2) * 8 + (w >> 3);
   x = gx * 32 + lx;
@@ -64,7 +66,7 @@ TDT_DEV uint32_t wave_sum(uint32_t v) {
 // is run per lane as a state machine, so lanes of one wave can be in different samples /
 // bounces / steps at the same time; every lane still executes exactly the reference's sequence
 // of operations for its own pixel, in the same order (bit-identical sums).
-enum : int { ST_TRAVERSE = 0, ST_HIT = 1, ST_END = 2, ST_FETCH = 3, ST_PRIMARY = 4, ST_NEWRAY = 5, ST_DONE = 6 };
+enum : int { ST_DONE = -1, ST_TRAVERSE = 0, ST_HIT = 1, ST_END = 2, ST_FETCH = 3, ST_PRIMARY = 4, ST_NEWRAY = 5 };   // events are the positive states
 
 // P.accumulate == 0: the whole of main() rc:234-252; 1: only the sample loop, adding to running sums (a uniform run-time
 // flag, looked at once per pixel, so the scene-specialised variants serve progressive passes too).
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     TDT_TICK(0);
     // ------------------------------------------------------------ path events
     const unsigned long long m_trav = __ballot(state == ST_TRAVERSE);
-    const unsigned long long m_event = __ballot(state != ST_TRAVERSE && state != ST_DONE);
+    const unsigned long long m_event = __ballot(state > ST_TRAVERSE);
     if (m_trav == 0ull && m_event == 0ull) break;
     w_steps += (uint32_t)__popcll(m_trav);            // lanes that take the next traversal step
     // run the (long, material-divergent) event code only when enough lanes wait for it (a separate
@@ -215,9 +217,9 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     TDT_TICK(1);
 
     if (COUNT) evpass_no++;
-    if (COUNT) { cnt.event_slots += slot64(); cnt.event_active += (state != ST_TRAVERSE && state != ST_DONE); }
-    lane_work += (state != ST_TRAVERSE && state != ST_DONE) ? kCostEvent : 0u;
-    if (COUNT) lane_E += (state != ST_TRAVERSE && state != ST_DONE) ? 1u : 0u;
+    if (COUNT) { cnt.event_slots += slot64(); cnt.event_active += (state > ST_TRAVERSE); }
+    lane_work += (state > ST_TRAVERSE) ? kCostEvent : 0u;
+    if (COUNT) lane_E += (state > ST_TRAVERSE) ? 1u : 0u;
     if (state == ST_HIT) {                            // RayColor loop body rc:272-295
       if (COUNT) { cnt.scatter_slots += slot64(); cnt.scatter_active++; }
       const MatRef mat = material_fetch(ms, hit_index);
@@ -816,6 +818,9 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
   Tiles t = tiles_of(c, k);
   P.cover_w = k.cover_w; P.cover_h = k.cover_h;
   P.tiles_x = t.tiles_x > 0 ? t.tiles_x : 1; P.owned_tiles = t.owned;
+  // t / tiles_x by multiplication: with m = floor(2^32 / d) + 1, mulhi(t, m) = floor(t / d) whenever t * d < 2^32
+  P.tiles_x_magic = ((unsigned long long)(t.total > 0 ? t.total : 1) * (unsigned long long)P.tiles_x < (1ull << 32) && P.tiles_x > 1)
+                        ? (uint32_t)((1ull << 32) / (unsigned long long)P.tiles_x) + 1u : 0u;
   P.part_rank = c->part_rank; P.part_world = c->part_world;
   if (img->w == c->image_width && img->h == c->image_height) P.compact = 0;
   else if (img->w == 32 && img->h >= 32 * t.owned && (img->h % 32) == 0) P.compact = 1;   // tile buffer [k][32][32]

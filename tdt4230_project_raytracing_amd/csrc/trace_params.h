@@ -31,6 +31,7 @@ struct TraceParams {
   int32_t compact;             // 1: image is this rank's tile buffer [owned tile k][32][32] RGBA
   int32_t cover_w, cover_h;    // pixels a dispatch covers: min(32*groups, image size)
   int32_t tiles_x;             // 32x32 work-groups per row = ceil(cover_w / 32)
+  uint32_t tiles_x_magic;      // floor(2^32 / tiles_x) + 1 when every work-group index t of the dispatch has t * tiles_x < 2^32 (then t / tiles_x = mulhi(t, magic)); else 0
   int32_t owned_tiles;         // work-groups this rank traces
   int32_t part_rank, part_world;  // work-group partition: tile t (row-major) belongs to rank t % world
   int32_t spp_begin, spp_count;   // sample range of this launch
