@@ -74,9 +74,9 @@ enum : int { ST_DONE = -1, ST_TRAVERSE = 0, ST_HIT = 1, ST_END = 2, ST_FETCH = 3
 // POW2: exact-comparison treeLookup (see tree_lookup_pow2) vs the literal float form.
 // PROBE changes nothing but the kernel's name: the short probe launch of a two-phase frame (tdt_dispatch_compute) then shows
 // up as its own row in profiler statistics instead of halving the average of the launches that do the work.
-template <bool COUNT, bool POW2, int DEPTH = 0, bool RESIDENT = false, bool SAFEV = false, bool PROBE = false, bool FULL = false, bool UNIT = false>
+template <bool COUNT, bool POW2, int DEPTH = 0, bool RESIDENT = false, bool SAFEV = false, bool PROBE = false, bool FULL = false, bool UNIT = false, bool BRICK = false>
 __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
-  __shared__ __attribute__((aligned(16))) uint16_t s_nodes[kLdsCells * 8 + 8];   // + the sentinel slot
+  __shared__ __attribute__((aligned(16))) uint16_t s_nodes[(BRICK ? kBrickLdsCells : kLdsCells) * 8 + 8];   // + the sentinel slot (BRICK: the host stages no more than fit)
   for (uint32_t i = threadIdx.x * 8u; i < P.lds_nodes; i += (uint32_t)TDT_BLOCK * 8u)      // one cell (8 x u16) per lane and trip
     *reinterpret_cast<uint4 *>(&s_nodes[i]) = *reinterpret_cast<const uint4 *>(&P.packed[i]);
   // sentinel: the rest of a partial last cell and one more cell (RESIDENT: all EMPTY, see tree_lookup_pow2), or the escape code
@@ -84,15 +84,22 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     s_nodes[P.lds_nodes + threadIdx.x] = (uint16_t)((RESIDENT && POW2) ? 0u : kPackedEscape);
   __syncthreads();
   constexpr int GL = RESIDENT ? 4 : 5;                                 // levels of the top-level jump table (see Grid<GL>)
-  constexpr bool kUseGrid = !FULL && !COUNT && POW2 && SAFEV && DEPTH >= GL;   // see build_top_grid (FULL: the whole-depth table in global memory instead)
+  constexpr bool kUseGrid = !FULL && !BRICK && !COUNT && POW2 && SAFEV && DEPTH >= GL;   // see build_top_grid (FULL: the whole-depth table in global memory instead; BRICK: the 32-bit table below)
   __shared__ typename Grid<GL>::Entry s_grid[kUseGrid ? Grid<GL>::kEntries : 1];
   __shared__ int s_grid_ok;
   if (kUseGrid) build_top_grid<GL>(s_nodes, P.lds_nodes, DEPTH, s_grid, &s_grid_ok);
+  __shared__ __attribute__((aligned(16))) uint32_t s_grid32[BRICK ? (1 << 15) : 4];     // BRICK: build_bricks_kernel's table, copied as it is
+  if (BRICK) {
+    for (uint32_t i = threadIdx.x * 4u; i < (1u << 15); i += (uint32_t)TDT_BLOCK * 4u)
+      *reinterpret_cast<uint4 *>(&s_grid32[i]) = *reinterpret_cast<const uint4 *>(&P.brick_grid[i]);
+    __syncthreads();
+  }
   NodeSource ns;
   ns.lds = s_nodes; ns.lds_nodes = P.lds_nodes; ns.lds_cells = (P.lds_nodes + 7u) >> 3;
   ns.grid = s_grid; ns.grid_ok = kUseGrid ? (__builtin_amdgcn_readfirstlane(s_grid_ok) != 0) : false;
   ns.grid_band = FULL ? Grid<5>::kBand : (ns.grid_ok ? Grid<GL>::kBand : 2.0f);
   ns.full = P.full_grid;
+  ns.grid32 = s_grid32; ns.bricks = P.bricks;
   ns.cells = __builtin_amdgcn_make_buffer_rsrc((void *)P.cells, 0, (int)((P.cells_dwords >> 1) << 3), 0x00020000);
   const MatSource ms = material_source(P);
   const uint32_t total_slots = (uint32_t)P.owned_tiles * 1024u;
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       if (inside) {
         float ugx, ugy, ugz; uint32_t value;
         if (COUNT) cnt.iterations++;
-        const bool leaf = POW2 ? tree_lookup_pow2<COUNT, kMemoLevels, DEPTH, RESIDENT, SAFEV, FULL>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, memo, cnt)
+        const bool leaf = POW2 ? tree_lookup_pow2<COUNT, kMemoLevels, DEPTH, RESIDENT, SAFEV, FULL, BRICK>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, memo, cnt)
                                : tree_lookup<COUNT>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, cnt);
         lane_work += kCostStep + (127u - (__float_as_uint(inv_pow_depth) >> 23));   // + tree levels visited (inv_pow_depth = 2^-levels)
         const float bx = (UNIT ? ugx : ugx * P.scale) + P.min_x, by = (UNIT ? ugy : ugy * P.scale) + P.min_y, bz = (UNIT ? ugz : ugz * P.scale) + P.min_z;
@@ -479,6 +486,85 @@ __global__ __launch_bounds__(256) void build_full_grid_kernel(const uint32_t *__
   if (!ok) atomicOr(bad, 1u);
 }
 
+// The bricks of BRICK builds (see tree_lookup_pow2): one block per level-5 position e = x5 << 10 | y5 << 5 | z5.  Every thread walks
+// the five levels above it as treeLookup would (digits of e; the bands keep the lanes away from coordinates where that is not
+// what the reference does); a position that holds a PARENT gets its 27 x 64 entries by walking on, once per decision sequence,
+// reading the real nodes (past the end of the buffer: zeros) — the 12 level-6 nodes and up to 144 level-7 nodes through LDS.
+// grid32[e] = what tree_lookup_pow2 decodes; e7 / e8 = 31 when the level-7 / level-8 cells reachable from here do not share
+// floor(log2(index)), an index is 0 or >= 2^20, or a LEAF value does not fit 10 bits: waves that meet such a position walk.
+// *bad: a PARENT above level 5 at or beyond grid_v_bound (the table's own claim does not hold: no BRICK build for this tree).
+__device__ __forceinline__ void brick_node(const uint32_t *__restrict__ cells, uint32_t cells_dwords, uint32_t idx, uint32_t &value, uint32_t &code) {
+  idx &= 0x1FFFFFFFu;
+  uint32_t type = 0; value = 0;
+  if (2u * idx + 1u < cells_dwords) { value = cells[2u * idx]; type = cells[2u * idx + 1u]; }     // reads past the end are 0 (robust access)
+  code = (type == 0u) ? 0u : (type == 2u ? 2u : 1u);
+}
+__global__ __launch_bounds__(256) void build_bricks_kernel(const uint32_t *__restrict__ cells, uint32_t cells_dwords, uint32_t *__restrict__ grid32,
+                                                           uint16_t *__restrict__ bricks, uint32_t *__restrict__ bad) {
+  const uint32_t e = blockIdx.x, xg = e >> 10, yg = (e >> 5) & 31u, zg = e & 31u, tid = threadIdx.x;
+  uint32_t v = 0, code = 1u, m = 0;
+  bool ok = true;
+  for (int l = 1; l <= 5 && code == 1u; l++) {
+    const int sh = 5 - l;
+    brick_node(cells, cells_dwords, ((2u * v + ((xg >> sh) & 1u)) << 2) + (((yg >> sh) & 1u) << 1) + ((zg >> sh) & 1u), v, code);
+    m = (uint32_t)l;
+    if (code == 1u && l < 5 && v >= grid_v_bound(l)) ok = false;          // this v feeds the next level's x decision
+  }
+  if (!ok && tid == 0) atomicOr(bad, 1u);
+  if (code != 1u) {                                   // EMPTY / LEAF within five levels
+    if (code == 2u && v >= (1u << 26) && tid == 0) atomicOr(bad, 1u);
+    if (tid == 0) grid32[e] = (code == 2u ? v << 6 : 0u) | (m << 2) | code;
+    return;
+  }
+  __shared__ uint32_t s6v[12], s6c[12], s7v[144], s7c[144], s_lo7, s_hi7, s_lo8, s_hi8, s_inv;
+  if (tid == 0) { s_lo7 = 31u; s_hi7 = 0u; s_lo8 = 31u; s_hi8 = 0u; s_inv = (v == 0u || v >= (1u << 20)) ? 1u : 0u; }
+  __syncthreads();
+  if (tid < 12) {                                     // the level-6 nodes: (a + b) x y x z
+    uint32_t w, c;
+    brick_node(cells, cells_dwords, ((2u * v + (tid >> 2)) << 2) + (tid & 3u), w, c);
+    s6v[tid] = w; s6c[tid] = c;
+    if (c == 1u) {
+      if (w == 0u || w >= (1u << 22)) atomicOr(&s_inv, 1u);
+      else { const uint32_t ex = 31u - (uint32_t)__builtin_clz(w); atomicMin(&s_lo7, ex); atomicMax(&s_hi7, ex); }
+    }
+  }
+  __syncthreads();
+  if (tid < 144) {                                    // the level-7 nodes below each level-6 PARENT
+    const uint32_t i6 = tid / 12u, i7 = tid % 12u;
+    uint32_t w = 0, c = 0;
+    if (s6c[i6] == 1u) {
+      brick_node(cells, cells_dwords, ((2u * s6v[i6] + (i7 >> 2)) << 2) + (i7 & 3u), w, c);
+      if (c == 1u) {
+        if (w == 0u || w >= (1u << 22)) atomicOr(&s_inv, 1u);
+        else { const uint32_t ex = 31u - (uint32_t)__builtin_clz(w); atomicMin(&s_lo8, ex); atomicMax(&s_hi8, ex); }
+      }
+    }
+    s7v[tid] = w; s7c[tid] = c;
+  }
+  __syncthreads();
+  for (uint32_t s = tid; s < kBrickEntries; s += 256u) {
+    const uint32_t ci = s >> 6, yz = s & 63u, c6 = ci / 9u, c7 = (ci / 3u) % 3u, c8 = ci % 3u;
+    const uint32_t i6 = (c6 << 2) | (((yz >> 5) & 1u) << 1) | ((yz >> 2) & 1u);
+    uint32_t val = s6v[i6], cd = s6c[i6], mm = 6u;
+    if (cd == 1u) {
+      const uint32_t i7 = (c7 << 2) | (((yz >> 4) & 1u) << 1) | ((yz >> 1) & 1u);
+      val = s7v[i6 * 12u + i7]; cd = s7c[i6 * 12u + i7]; mm = 7u;
+      if (cd == 1u) {
+        brick_node(cells, cells_dwords, ((2u * val + c8) << 2) + (((yz >> 3) & 1u) << 1) + (yz & 1u), val, cd);
+        mm = 8u;
+      }
+    }
+    if (cd == 2u && val >= 1024u) atomicOr(&s_inv, 1u);
+    bricks[(size_t)e * kBrickEntries + s] = (uint16_t)((cd == 2u ? val << 6 : 0u) | (mm << 2) | cd);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const bool shared7 = s_lo7 == 31u || s_lo7 == s_hi7, shared8 = s_lo8 == 31u || s_lo8 == s_hi8;     // (31: no PARENT on that level)
+    const uint32_t e7 = s_lo7 == 31u ? 0u : s_lo7, e8 = s_lo8 == 31u ? 0u : s_lo8;
+    grid32[e] = (s_inv == 0u && shared7 && shared8) ? (1u | (e7 << 2) | (e8 << 7) | (v << 12)) : (1u | (31u << 2) | ((v & 0xFFFFFu) << 12));
+  }
+}
+
 // Exhaustive check of the short correctly-rounded forms against the IEEE expressions: every one of
 // the 2^32 float bit patterns (NaN results compare equal to NaN results).  which: 0 rcp, 1 sqrt, 2 rsq.
 __global__ __launch_bounds__(256) void selftest_kernel(int which, unsigned long long *mismatches) {
@@ -533,6 +619,21 @@ __global__ __launch_bounds__(256) void selftest_kernel(int which, unsigned long 
                           (__float_as_uint(f.ny) == __float_as_uint(l.ny) || (f.ny != f.ny && l.ny != l.ny)) &&
                           (__float_as_uint(f.nz) == __float_as_uint(l.nz) || (f.nz != f.nz && l.nz != l.nz)) && f.ff == l.ff;
         bad += same ? 0u : 1u;
+      }
+      continue;
+    }
+    if (which == 13 || which == 14) {
+      // the bricks' claim: fl(v + f) - v depends on an integer v < 2^22 only through e = floor(log2 v) — for every f in [0, 1) and
+      // the ends, the middle and the neighbours of the ends of every binade.  14: the harness (the next binade's value must differ).
+      if (!(x >= 0.0f && x < 1.0f)) continue;
+      for (uint32_t e = 0; e < 22u; e++) {
+        const float q = brick_q(which == 13 ? e : e + 1u, x);
+        const uint32_t lo = 1u << e, vs[5] = {lo, lo + 1u, lo + (lo >> 1) + (lo >> 3), 2u * lo - 2u, 2u * lo - 1u};
+        for (int k = 0; k < 5; k++) {
+          const uint32_t v = vs[k] < lo ? lo : (vs[k] > 2u * lo - 1u ? 2u * lo - 1u : vs[k]);
+          const float fv = (float)v;
+          bad += (__float_as_uint((fv + x) - fv) == __float_as_uint(q)) ? 0u : 1u;
+        }
       }
       continue;
     }
@@ -970,13 +1071,40 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
       full = ctx->full_ok;
       P.full_grid = ctx->full_grid;
     }
+    // depth-8 trees that are not LDS-resident: bricks (tree_lookup_pow2 BRICK), built once per cells buffer
+    bool brick = false;
+    if (mode != 2 && !counts_out && pow2 && safev && !resident && !ctx->no_specialise && !ctx->no_bricks && P.max_depth == 8) {
+      const tdt_buffer *cb = ctx->ssbo[TDT_SLOT_CELLS];
+      if (ctx->brick_of != cb || ctx->brick_version != cb->version) {
+        if (!ctx->brick_grid) TDT_HIP(ctx, hipMalloc((void **)&ctx->brick_grid, ((size_t)1 << 15) * sizeof(uint32_t) + sizeof(uint32_t)));
+        if (!ctx->bricks) TDT_HIP(ctx, hipMalloc((void **)&ctx->bricks, ((size_t)1 << 15) * tdt::kBrickEntries * sizeof(uint16_t)));
+        uint32_t *bad = ctx->brick_grid + ((size_t)1 << 15);
+        TDT_HIP(ctx, hipMemsetAsync(bad, 0, sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(tdt::build_bricks_kernel, dim3(1u << 15), dim3(256), 0, ctx->stream, P.cells, P.cells_dwords, ctx->brick_grid, ctx->bricks, bad);
+        TDT_HIP(ctx, hipGetLastError());
+        uint32_t flag = 1;
+        TDT_HIP(ctx, hipMemcpyAsync(&flag, bad, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
+        TDT_HIP(ctx, hipStreamSynchronize(ctx->stream));    // once per cells buffer (version), not per frame
+        ctx->brick_of = cb; ctx->brick_version = cb->version; ctx->brick_ok = flag == 0;
+      }
+      brick = ctx->brick_ok;
+      if (brick) {
+        P.brick_grid = ctx->brick_grid; P.bricks = ctx->bricks;
+        if (P.lds_nodes > tdt::kBrickLdsCells * 8u) P.lds_nodes = tdt::kBrickLdsCells * 8u;      // (the BRICK builds' LDS node table)
+      }
+    }
     if (mode != 2 && !counts_out && pow2 && safev && !ctx->no_specialise) {
       const bool unit = P.scale == 1.0f && P.inv_scale == 1.0f;          // x * 1.0f is x: the UNIT builds do not multiply
+#define TDT_BRICK1(U) if (ctx->probe_launch) hipLaunchKernelGGL((tdt::trace_kernel<false, true, 8, false, true, true, false, U, true>), grid, block, 0, ctx->stream, P); \
+                      else hipLaunchKernelGGL((tdt::trace_kernel<false, true, 8, false, true, false, false, U, true>), grid, block, 0, ctx->stream, P)
+      if (brick) { if (unit) TDT_BRICK1(true); else TDT_BRICK1(false); launched = true; }
+#undef TDT_BRICK1
 #define TDT_SPEC4(D, R, F, U) if (ctx->probe_launch) hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, R, true, true, F, U>), grid, block, 0, ctx->stream, P); \
                               else hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, R, true, false, F, U>), grid, block, 0, ctx->stream, P)
 #define TDT_SPEC(D, R) if (unit) TDT_SPEC4(D, R, false, true); else TDT_SPEC4(D, R, false, false); launched = true; break
 #define TDT_SPEC_FULL(D) if (unit) TDT_SPEC4(D, true, true, true); else TDT_SPEC4(D, true, true, false); launched = true; break
-      if (full) switch (P.max_depth) { case 5: TDT_SPEC_FULL(5); case 6: TDT_SPEC_FULL(6); default: break; }
+      if (launched) {}
+      else if (full) switch (P.max_depth) { case 5: TDT_SPEC_FULL(5); case 6: TDT_SPEC_FULL(6); default: break; }
       else
       if (resident) switch (P.max_depth) {
         case 3: TDT_SPEC(3, true); case 4: TDT_SPEC(4, true); case 5: TDT_SPEC(5, true); case 6: TDT_SPEC(6, true);
@@ -1050,6 +1178,7 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
     ctx->no_cost_accum = getenv("TDT_NO_COST_ACCUM") != nullptr;
     ctx->no_two_phase = getenv("TDT_NO_TWO_PHASE") != nullptr;
     ctx->no_full = getenv("TDT_NO_FULL_GRID") != nullptr;
+    ctx->no_bricks = getenv("TDT_NO_BRICKS") != nullptr;
     const char *ms = getenv("TDT_MAX_SHARE"); ctx->max_share = ms ? (float)atof(ms) : 1.0f;
     const char *ob = getenv("TDT_ORDER_BLEND"); ctx->order_blend = ob ? (float)atof(ob) : 0.5f;
     const char *pd = getenv("TDT_PROBE_DIV"); ctx->probe_div = pd && atoi(pd) >= 2 && atoi(pd) <= 64 ? atoi(pd) : 16; }
@@ -1089,6 +1218,8 @@ void tdt_ctx_destroy(tdt_ctx *ctx) {
   if (ctx->present) (void)hipFree(ctx->present);
   if (ctx->frame_carry) (void)hipFree(ctx->frame_carry);
   if (ctx->full_grid) (void)hipFree(ctx->full_grid);
+  if (ctx->brick_grid) (void)hipFree(ctx->brick_grid);
+  if (ctx->bricks) (void)hipFree(ctx->bricks);
   if (ctx->phase_timing) for (auto &e : ctx->phase_ev) (void)hipEventDestroy(e);
   tdt::edit_scratch_destroy(ctx);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -1527,7 +1658,7 @@ int tdt_debug_wave_ends(tdt_ctx *ctx, uint64_t *out, int n) {
 /* Exhaustive self-test of the kernels' short correctly-rounded rcp / sqrt / rsq forms against the
  * IEEE expressions on all 2^32 inputs; *mismatches must come back 0 (which: 0 rcp, 1 sqrt, 2 rsq). */
 int tdt_selftest(tdt_ctx *ctx, int which, uint64_t *mismatches) {
-  if (!ctx || !mismatches || which < 0 || which > 12) return TDT_ERR_INVALID_VALUE;
+  if (!ctx || !mismatches || which < 0 || which > 14) return TDT_ERR_INVALID_VALUE;
   TDT_HIP(ctx, hipSetDevice(ctx->device));
   if (!ctx->counters) TDT_HIP(ctx, hipMalloc((void **)&ctx->counters, (32 + 16384 + 256) * sizeof(unsigned long long)));
   TDT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));

@@ -180,6 +180,7 @@ struct NodeSource {
   const void *grid;                                   // top-level jump table (Grid<GL>::Entry[], see build_top_grid), or unusable when !grid_ok
   bool grid_ok; float grid_band;                      // grid_band = kGridBand, or 2 when the table is unusable
   const uint16_t *full;                               // FULL builds: the whole-depth table in global memory (see tree_lookup_pow2)
+  const uint32_t *grid32; const uint16_t *bricks;     // BRICK builds: the 5-level table with brick headers (LDS) and the bricks (global memory)
   __amdgpu_buffer_rsrc_t cells;                       // raw buffer over the cells payload (8-byte granules)
 };
 
@@ -434,7 +435,25 @@ constexpr int kMemoFirst = 3;       // levels 1..3 = cells 0..72 at most: always
 // read through L2) holds what the whole descent ends on, so a traversal step does ONE load instead of a table read plus two
 // more levels; the bands are those of the 5-level table (cell indices of a resident tree stay below 8192: 2^-11 around the
 // integers of 2^depth c), and a wave with a lane inside one walks all levels from the LDS node table.
-template <bool COUNT, int CL, int DEPTH, bool RESIDENT, bool SAFEV, bool FULL = false>
+// BRICK (round 2; depth-8 trees that are NOT LDS-resident, every PARENT value < 2^22): levels 6-8 in ONE load as well.  Below
+// level 5 cell indices are large and the x decision  a = fl(v + f) - v > 0.5, b = ... == 1  is far from the coordinate's binary
+// digit (v ~ 2^20: ulp(v + f) = 2^-3), so a table indexed by position would be wrong for a tenth of all coordinates.  But for
+// an integer v < 2^22 the sum v + f is rounded on a grid of 2^(e-23), e = floor(log2 v), that v itself lies on, with ties
+// that do not depend on v: fl(v + f) - v is a function of e and f alone (checked for every f in [0,1) x every e x the ends
+// and the middle of its binade: tdt_selftest 13).  And the cells of one level below one level-5 position are neighbours in the
+// breadth-first array, so they share e.  Hence a "brick" per level-5 position, indexed not by position but by DECISION
+// sequence — (a + b) of levels 6, 7, 8 (27 combinations) x the three y and three z digits (64) — holds exactly what the
+// reference's walk ends on, 2v + 2 jumps into the neighbour cell included, because build_bricks_kernel fills it by doing that
+// walk; the level-5 table entry carries the level-6 cell index (the level-6 decision uses it as it is) and the exponents e7, e8
+// for the decisions of levels 7 and 8 (31: the cells below this position do not share one — the wave walks).  A traversal
+// step is then one LDS read and one 2-byte load instead of a table read, three memo compares and up to three dependent L2
+// round trips.  Table entries (32 bits): PARENT 1 | e7 << 2 | e8 << 7 | v << 12; EMPTY / LEAF value << 6 | levels << 2 | code.
+// Brick entries (16 bits): levels << 2 | code, and a LEAF's value << 6 (a material index >= 1024 below a position: it walks).
+constexpr uint32_t kBrickEntries = 27u * 64u;         // per level-5 position (2 bytes each; 32768 positions: 113 MB of address space, touched where the tree is)
+constexpr uint32_t kBrickLdsCells = 1024u;            // BRICK builds keep a small node table (the walk of waves with a lane in a band starts in it)
+// fl(v + f) - v for any integer v in [2^e, 2^(e+1)), e <= 21
+TDT_DEV float brick_q(uint32_t e, float f) { const float V = __uint_as_float((127u + e) << 23); return (V + f) - V; }
+template <bool COUNT, int CL, int DEPTH, bool RESIDENT, bool SAFEV, bool FULL = false, bool BRICK = false>
 TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float fx, float fy, float fz, float &inv_pow_depth,
                               float &gx, float &gy, float &gz, uint32_t &value, NodeMemo<CL> &memo, Counters &cnt) {
   const int depth = DEPTH > 0 ? DEPTH : P.max_depth;
@@ -464,6 +483,33 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
       inv_pow_depth = ipd;
       value = g >> 5;
       return (g & 3u) == 2u;
+    }
+  } else if constexpr (BRICK && !COUNT) {
+    static_assert(!BRICK || (DEPTH == 8 && !RESIDENT && SAFEV), "bricks: depth-8 trees outside the LDS table");
+    const float tg = fx0 * 32.0f;                     // exact
+    const uint32_t xg = (uint32_t)tg;
+    const uint32_t e = (xg << 10) | ((Yi >> 3) << 5) | (Zi >> 3);
+    const uint32_t g = ns.grid32[e];
+    const bool parent = (g & 3u) == 1u;
+    const bool ok = __builtin_fabsf(tg - __builtin_rintf(tg)) > Grid<5>::kBand && !(parent && ((g >> 2) & 31u) == 31u);
+    if (__builtin_expect(__ballot(!ok) == 0ull, 1)) {
+      uint32_t ent = g, xd = xg << 3;                 // what the descent ends on; its eight x digits (the top `levels` count)
+      if (parent) {
+        const float f6 = f_fract_nonneg(tg), f7 = f_fract_nonneg(fx0 * 64.0f), f8 = f_fract_nonneg(fx0 * 128.0f);
+        const float fv = (float)(g >> 12);
+        const float q6 = (fv + f6) - fv, q7 = brick_q((g >> 2) & 31u, f7), q8 = brick_q((g >> 7) & 31u, f8);
+        const uint32_t a6 = q6 > 0.5f ? 1u : 0u, b6 = q6 == 1.0f ? 1u : 0u, a7 = q7 > 0.5f ? 1u : 0u, b7 = q7 == 1.0f ? 1u : 0u,
+                       a8 = q8 > 0.5f ? 1u : 0u, b8 = q8 == 1.0f ? 1u : 0u;
+        const uint32_t ci = ((a6 + b6) * 3u + (a7 + b7)) * 3u + (a8 + b8);
+        ent = ns.bricks[e * kBrickEntries + ((ci << 6) | ((Yi & 7u) << 3) | (Zi & 7u))];
+        xd |= ((a6 & ~b6) << 2) | ((a7 & ~b7) << 1) | (a8 & ~b8);
+      }
+      const uint32_t mg = (ent >> 2) & 15u, sh = 8u - mg;
+      const float ipd = __uint_as_float((127u - mg) << 23);                   // 2^-levels
+      gx = (float)(xd >> sh) * ipd; gy = (float)(Yi >> sh) * ipd; gz = (float)(Zi >> sh) * ipd;
+      inv_pow_depth = ipd;
+      value = ent >> 6;
+      return (ent & 3u) == 2u;
     }
   } else if constexpr (!COUNT && DEPTH >= kTableLevels) {        // the top levels in one step (see build_top_grid)
     const float tg = fx0 * (float)(1 << kGridLevels);  // exact

@@ -353,3 +353,5 @@ def test_short_rounding_forms_exhaustively():
         assert ctx.selftest(10) > 0      # ... and not without the guard
         assert ctx.selftest(11) == 0     # (m-1)/(m+1) and (1-x)/(1+x) through reciprocal + residual step == IEEE division
         assert ctx.selftest(12) > 0
+        assert ctx.selftest(13) == 0     # fl(v + f) - v is a function of floor(log2 v) and f (the bricks of depth-8 trees)
+        assert ctx.selftest(14) > 0
