@@ -72,7 +72,7 @@ struct tdt_ctx {
   void *frame_carry; size_t frame_carry_bytes;   // hit-record carry between the two phases of a frame (tdt_dispatch_compute)
   bool no_two_phase;                             // TDT_NO_TWO_PHASE=1
   uint16_t *full_grid; const tdt_buffer *full_of; unsigned long long full_version; int full_depth; bool full_ok, no_full;   // whole-depth lookup table of small resident trees (TDT_NO_FULL_GRID=1: off)
-  uint32_t *brick_grid; uint16_t *bricks; const tdt_buffer *brick_of; unsigned long long brick_version; bool brick_ok, no_bricks;   // BRICK builds (depth-8 trees that are not LDS-resident; TDT_NO_BRICKS=1: off)
+  uint32_t *brick_grid; void *bricks; size_t bricks_bytes; const tdt_buffer *brick_of; unsigned long long brick_version; int brick_depth; bool brick_ok, no_bricks;   // BRICK builds (depth-8 / 9 trees that are not LDS-resident; TDT_NO_BRICKS=1: off)
   bool carry_final;                              // set around the last launch of a two-phase frame: its records need not be stored
   bool probe_launch;                             // set around the probe launch of a two-phase frame (kernel name only)
   bool phase_timing; hipEvent_t phase_ev[4]; int phase_n;   // tdt_debug_phase_timing: events around the launches of the last frame

@@ -499,8 +499,10 @@ __device__ __forceinline__ void brick_node(const uint32_t *__restrict__ cells, u
   if (2u * idx + 1u < cells_dwords) { value = cells[2u * idx]; type = cells[2u * idx + 1u]; }     // reads past the end are 0 (robust access)
   code = (type == 0u) ? 0u : (type == 2u ? 2u : 1u);
 }
+template <typename Entry>                              // uint16_t: depth-8 trees; uint32_t: depth 9 (a level-8 PARENT's value goes with the entry: level 9 is walked)
 __global__ __launch_bounds__(256) void build_bricks_kernel(const uint32_t *__restrict__ cells, uint32_t cells_dwords, uint32_t *__restrict__ grid32,
-                                                           uint16_t *__restrict__ bricks, uint32_t *__restrict__ bad) {
+                                                           Entry *__restrict__ bricks, uint32_t *__restrict__ bad) {
+  constexpr bool kWide = sizeof(Entry) == 4;
   const uint32_t e = blockIdx.x, xg = e >> 10, yg = (e >> 5) & 31u, zg = e & 31u, tid = threadIdx.x;
   uint32_t v = 0, code = 1u, m = 0;
   bool ok = true;
@@ -554,8 +556,9 @@ __global__ __launch_bounds__(256) void build_bricks_kernel(const uint32_t *__res
         mm = 8u;
       }
     }
-    if (cd == 2u && val >= 1024u) atomicOr(&s_inv, 1u);
-    bricks[(size_t)e * kBrickEntries + s] = (uint16_t)((cd == 2u ? val << 6 : 0u) | (mm << 2) | cd);
+    if (cd == 2u && val >= (kWide ? (1u << 26) : 1024u)) atomicOr(&s_inv, 1u);
+    if (kWide && cd == 1u && (val == 0u || val >= (1u << 22))) atomicOr(&s_inv, 1u);
+    bricks[(size_t)e * kBrickEntries + s] = (Entry)(((cd == 2u || (kWide && cd == 1u)) ? val << 6 : 0u) | (mm << 2) | cd);
   }
   __syncthreads();
   if (tid == 0) {
@@ -1073,19 +1076,26 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     }
     // depth-8 trees that are not LDS-resident: bricks (tree_lookup_pow2 BRICK), built once per cells buffer
     bool brick = false;
-    if (mode != 2 && !counts_out && pow2 && safev && !resident && !ctx->no_specialise && !ctx->no_bricks && P.max_depth == 8) {
+    if (mode != 2 && !counts_out && pow2 && safev && !resident && !ctx->no_specialise && !ctx->no_bricks && (P.max_depth == 8 || P.max_depth == 9)) {
       const tdt_buffer *cb = ctx->ssbo[TDT_SLOT_CELLS];
-      if (ctx->brick_of != cb || ctx->brick_version != cb->version) {
+      if (ctx->brick_of != cb || ctx->brick_version != cb->version || ctx->brick_depth != P.max_depth) {
+        const size_t need = ((size_t)1 << 15) * tdt::kBrickEntries * (P.max_depth == 9 ? sizeof(uint32_t) : sizeof(uint16_t));
         if (!ctx->brick_grid) TDT_HIP(ctx, hipMalloc((void **)&ctx->brick_grid, ((size_t)1 << 15) * sizeof(uint32_t) + sizeof(uint32_t)));
-        if (!ctx->bricks) TDT_HIP(ctx, hipMalloc((void **)&ctx->bricks, ((size_t)1 << 15) * tdt::kBrickEntries * sizeof(uint16_t)));
+        if (ctx->bricks_bytes < need) {
+          if (ctx->bricks) (void)hipFree(ctx->bricks);
+          ctx->bricks = nullptr; ctx->bricks_bytes = 0; ctx->brick_of = nullptr;
+          TDT_HIP(ctx, hipMalloc(&ctx->bricks, need));
+          ctx->bricks_bytes = need;
+        }
         uint32_t *bad = ctx->brick_grid + ((size_t)1 << 15);
         TDT_HIP(ctx, hipMemsetAsync(bad, 0, sizeof(uint32_t), ctx->stream));
-        hipLaunchKernelGGL(tdt::build_bricks_kernel, dim3(1u << 15), dim3(256), 0, ctx->stream, P.cells, P.cells_dwords, ctx->brick_grid, ctx->bricks, bad);
+        if (P.max_depth == 9) hipLaunchKernelGGL(tdt::build_bricks_kernel<uint32_t>, dim3(1u << 15), dim3(256), 0, ctx->stream, P.cells, P.cells_dwords, ctx->brick_grid, static_cast<uint32_t *>(ctx->bricks), bad);
+        else hipLaunchKernelGGL(tdt::build_bricks_kernel<uint16_t>, dim3(1u << 15), dim3(256), 0, ctx->stream, P.cells, P.cells_dwords, ctx->brick_grid, static_cast<uint16_t *>(ctx->bricks), bad);
         TDT_HIP(ctx, hipGetLastError());
         uint32_t flag = 1;
         TDT_HIP(ctx, hipMemcpyAsync(&flag, bad, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
         TDT_HIP(ctx, hipStreamSynchronize(ctx->stream));    // once per cells buffer (version), not per frame
-        ctx->brick_of = cb; ctx->brick_version = cb->version; ctx->brick_ok = flag == 0;
+        ctx->brick_of = cb; ctx->brick_version = cb->version; ctx->brick_depth = P.max_depth; ctx->brick_ok = flag == 0;
       }
       brick = ctx->brick_ok;
       if (brick) {
@@ -1095,9 +1105,10 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     }
     if (mode != 2 && !counts_out && pow2 && safev && !ctx->no_specialise) {
       const bool unit = P.scale == 1.0f && P.inv_scale == 1.0f;          // x * 1.0f is x: the UNIT builds do not multiply
-#define TDT_BRICK1(U) if (ctx->probe_launch) hipLaunchKernelGGL((tdt::trace_kernel<false, true, 8, false, true, true, false, U, true>), grid, block, 0, ctx->stream, P); \
-                      else hipLaunchKernelGGL((tdt::trace_kernel<false, true, 8, false, true, false, false, U, true>), grid, block, 0, ctx->stream, P)
-      if (brick) { if (unit) TDT_BRICK1(true); else TDT_BRICK1(false); launched = true; }
+#define TDT_BRICK1(D, U) if (ctx->probe_launch) hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, false, true, true, false, U, true>), grid, block, 0, ctx->stream, P); \
+                         else hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, false, true, false, false, U, true>), grid, block, 0, ctx->stream, P)
+      if (brick && P.max_depth == 8) { if (unit) TDT_BRICK1(8, true); else TDT_BRICK1(8, false); launched = true; }
+      if (brick && P.max_depth == 9) { if (unit) TDT_BRICK1(9, true); else TDT_BRICK1(9, false); launched = true; }
 #undef TDT_BRICK1
 #define TDT_SPEC4(D, R, F, U) if (ctx->probe_launch) hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, R, true, true, F, U>), grid, block, 0, ctx->stream, P); \
                               else hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, R, true, false, F, U>), grid, block, 0, ctx->stream, P)

@@ -180,7 +180,7 @@ struct NodeSource {
   const void *grid;                                   // top-level jump table (Grid<GL>::Entry[], see build_top_grid), or unusable when !grid_ok
   bool grid_ok; float grid_band;                      // grid_band = kGridBand, or 2 when the table is unusable
   const uint16_t *full;                               // FULL builds: the whole-depth table in global memory (see tree_lookup_pow2)
-  const uint32_t *grid32; const uint16_t *bricks;     // BRICK builds: the 5-level table with brick headers (LDS) and the bricks (global memory)
+  const uint32_t *grid32; const void *bricks;         // BRICK builds: the 5-level table with brick headers (LDS) and the bricks (global memory: 16-bit entries for depth 8, 32-bit for depth 9)
   __amdgpu_buffer_rsrc_t cells;                       // raw buffer over the cells payload (8-byte granules)
 };
 
@@ -469,7 +469,7 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
   const float fx0 = fx;
   bool jumped = false;
   constexpr int kTableLevels = RESIDENT ? 4 : 5;                      // (see Grid<GL>)
-  constexpr int kGridLevels = FULL ? DEPTH : kTableLevels;            // levels the jump covers
+  constexpr int kGridLevels = FULL ? DEPTH : (BRICK ? 8 : kTableLevels);   // levels the jump covers
   if constexpr (FULL && !COUNT) {
     const float tg = fx0 * (float)(1 << DEPTH);       // exact
     const bool safe = __builtin_fabsf(tg - __builtin_rintf(tg)) > ns.grid_band;
@@ -485,10 +485,10 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
       return (g & 3u) == 2u;
     }
   } else if constexpr (BRICK && !COUNT) {
-    static_assert(!BRICK || (DEPTH == 8 && !RESIDENT && SAFEV), "bricks: depth-8 trees outside the LDS table");
+    static_assert(!BRICK || ((DEPTH == 8 || DEPTH == 9) && !RESIDENT && SAFEV), "bricks: depth-8 / depth-9 trees outside the LDS table");
     const float tg = fx0 * 32.0f;                     // exact
     const uint32_t xg = (uint32_t)tg;
-    const uint32_t e = (xg << 10) | ((Yi >> 3) << 5) | (Zi >> 3);
+    const uint32_t e = (xg << 10) | ((Yi >> (DEPTH - 5)) << 5) | (Zi >> (DEPTH - 5));
     const uint32_t g = ns.grid32[e];
     const bool parent = (g & 3u) == 1u;
     const bool ok = __builtin_fabsf(tg - __builtin_rintf(tg)) > Grid<5>::kBand && !(parent && ((g >> 2) & 31u) == 31u);
@@ -501,15 +501,24 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
         const uint32_t a6 = q6 > 0.5f ? 1u : 0u, b6 = q6 == 1.0f ? 1u : 0u, a7 = q7 > 0.5f ? 1u : 0u, b7 = q7 == 1.0f ? 1u : 0u,
                        a8 = q8 > 0.5f ? 1u : 0u, b8 = q8 == 1.0f ? 1u : 0u;
         const uint32_t ci = ((a6 + b6) * 3u + (a7 + b7)) * 3u + (a8 + b8);
-        ent = ns.bricks[e * kBrickEntries + ((ci << 6) | ((Yi & 7u) << 3) | (Zi & 7u))];
+        const uint32_t bi = e * kBrickEntries + ((ci << 6) | (((Yi >> (DEPTH - 8)) & 7u) << 3) | ((Zi >> (DEPTH - 8)) & 7u));
+        ent = DEPTH == 8 ? (uint32_t)static_cast<const uint16_t *>(ns.bricks)[bi] : static_cast<const uint32_t *>(ns.bricks)[bi];
         xd |= ((a6 & ~b6) << 2) | ((a7 & ~b7) << 1) | (a8 & ~b8);
       }
-      const uint32_t mg = (ent >> 2) & 15u, sh = 8u - mg;
-      const float ipd = __uint_as_float((127u - mg) << 23);                   // 2^-levels
-      gx = (float)(xd >> sh) * ipd; gy = (float)(Yi >> sh) * ipd; gz = (float)(Zi >> sh) * ipd;
-      inv_pow_depth = ipd;
-      value = ent >> 6;
-      return (ent & 3u) == 2u;
+      const uint32_t mg = (ent >> 2) & 15u;
+      if constexpr (DEPTH == 8) {                     // the whole lookup
+        const uint32_t sh = 8u - mg;
+        const float ipd = __uint_as_float((127u - mg) << 23);                 // 2^-levels
+        gx = (float)(xd >> sh) * ipd; gy = (float)(Yi >> sh) * ipd; gz = (float)(Zi >> sh) * ipd;
+        inv_pow_depth = ipd;
+        value = ent >> 6;
+        return (ent & 3u) == 2u;
+      } else {                                        // depth 9: the last level is walked (its PARENT's value came with the entry)
+        v = ent >> 6; code = ent & 3u;
+        qx = (1u << mg) | (xd >> (8u - mg));
+        fx = f_fract_nonneg(fx0 * 256.0f);            // fract(c * 2^8): level 9's coordinate
+        jumped = true;
+      }
     }
   } else if constexpr (!COUNT && DEPTH >= kTableLevels) {        // the top levels in one step (see build_top_grid)
     const float tg = fx0 * (float)(1 << kGridLevels);  // exact
