@@ -99,6 +99,42 @@ def test_relocated_top_cells_disable_the_jump_table(oracle):
         r.close()
 
 
+@pytest.mark.parametrize("cfg,case", [(3, "wide_materials"), (5, "wide_materials"), (3, "scattered_cells"), (5, "scattered_cells"), (3, "zero_child")])
+def test_positions_whose_bricks_cannot_be_built_walk(oracle, cfg, case):
+    """The bricks of depth-8 / 9 trees (build_bricks_kernel) mark a level-5 position whose sub-tree they cannot represent — a
+    material index that does not fit the entry, level-7 / level-8 cells that do not share floor(log2(index)), a PARENT that
+    points at cell 0 — and waves that meet one walk the levels: same bits as the oracle, next to positions that do have bricks."""
+    scene = host.Scene.config(cfg)
+    cells = scene.blobs[0].reshape(-1, 8, 2).copy()
+    rng = np.random.default_rng(11 + cfg)
+    leaves = np.argwhere(cells[:, :, 1] == 2)
+    parents = np.argwhere(cells[:, :, 1] == 1)
+    if case == "wide_materials":                                   # every third LEAF: an index past what a 16-bit entry holds
+        pick = leaves[rng.random(len(leaves)) < 0.33]              # (beyond the material table: robust access reads zeros)
+        cells[pick[:, 0], pick[:, 1], 0] += 70000 if cfg == 5 else 3000
+        cells[pick[::7, 0], pick[::7, 1], 0] += 1 << 26
+    elif case == "scattered_cells":                                # deep cells re-allocated far away (what edits do): other binades
+        deep = parents[parents[:, 0] > 5000]
+        pick = deep[rng.choice(len(deep), size=min(400, len(deep)), replace=False)]
+        n = cells.shape[0]
+        pad = (1 << 21) + 5 - n if cfg == 3 else 64                # config 3: past 2^21 (another exponent AND >= 2^20 for level-6 cells)
+        moved = cells[cells[pick[:, 0], pick[:, 1], 0].astype(np.int64)].copy()
+        cells = np.concatenate([cells, np.zeros((max(pad, 0), 8, 2), np.uint32), moved], axis=0)
+        cells[pick[:, 0], pick[:, 1], 0] = n + max(pad, 0) + np.arange(len(pick), dtype=np.uint32)
+    else:                                                          # a PARENT whose value is 0: the walk re-enters the root cell
+        pick = parents[parents[:, 0] > 600][::97]
+        cells[pick[:, 0], pick[:, 1], 0] = 0
+    scene.blobs[0] = np.ascontiguousarray(cells.reshape(-1))
+    cam = host.camera_reference_pose(192, 112, 4, 6)
+    ref = oracle.render(scene, cam, threads=8)
+    r = rt.Renderer(scene, cam)
+    try:
+        for _ in range(2):
+            assert _bits_equal(r.render(), ref).all()
+    finally:
+        r.close()
+
+
 @pytest.mark.parametrize("cfg,scale", [(2, 2.0), (2, 0.75), (3, 2.0), (1, 3.0)])
 def test_octree_scale_other_than_one(oracle, cfg, scale):
     """Octree::new takes any scale (main.rs:455-463 passes 1.0, and the kernels have builds that skip the multiplications by an
