@@ -251,9 +251,10 @@ int tdt_debug_pixel_log(tdt_ctx *ctx, uint32_t *out, size_t n_u32);
  * denormal, inf and NaN components: where its guard holds it returns the bits of the literal normalise-orient-normalise
  * sequence); and of the two one-parameter divisions taken through reciprocal + residual step (11: pow's (m - 1) / (m + 1) for
  * every mantissa, reflectance's (1 - x) / (1 + x) for every x); and of the claim the bricks of depth-8 trees rest on (13:
- * fl(v + f) - v depends on an integer v < 2^22 only through floor(log2 v), for every f in [0, 1)).  *mismatches must be 0.
- * Modes 3, 6, 8, 10, 12 and 14 check the harness: the raw reciprocal seed, the claims without the bands, the short normal
- * without its guard, the divisions without the residual step, and the wrong binade, must fail. */
+ * fl(v + f) - v depends on an integer v < 2^22 only through floor(log2 v), for every f in [0, 1); 15: the bands of their
+ * level-5 table, one per cell index instead of one for all).  *mismatches must be 0.  Modes 3, 6, 8, 10, 12, 14 and 16 check the
+ * harness: the raw reciprocal seed, the claims without the bands, the short normal without its guard, the divisions without
+ * the residual step, the wrong binade, and half the band, must fail. */
 int tdt_selftest(tdt_ctx *ctx, int which, uint64_t *mismatches);
 
 #ifdef __cplusplus

@@ -490,8 +490,9 @@ __global__ __launch_bounds__(256) void build_full_grid_kernel(const uint32_t *__
 // the five levels above it as treeLookup would (digits of e; the bands keep the lanes away from coordinates where that is not
 // what the reference does); a position that holds a PARENT gets its 27 x 64 entries by walking on, once per decision sequence,
 // reading the real nodes (past the end of the buffer: zeros) — the 12 level-6 nodes and up to 144 level-7 nodes through LDS.
-// grid32[e] = what tree_lookup_pow2 decodes; e7 / e8 = 31 when the level-7 / level-8 cells reachable from here do not share
-// floor(log2(index)), an index is 0 or >= 2^20, or a LEAF value does not fit 10 bits: waves that meet such a position walk.
+// grid32[e] = what tree_lookup_pow2 decodes; e7 = 31 when the level-7 / level-8 cells reachable from here do not share
+// floor(log2(index)), an index is 0 or does not fit (level-6 cell >= 2^17), or a LEAF value does not fit the entry: waves that
+// meet such a position walk.
 // *bad: a PARENT above level 5 at or beyond grid_v_bound (the table's own claim does not hold: no BRICK build for this tree).
 __device__ __forceinline__ void brick_node(const uint32_t *__restrict__ cells, uint32_t cells_dwords, uint32_t idx, uint32_t &value, uint32_t &code) {
   idx &= 0x1FFFFFFFu;
@@ -506,20 +507,24 @@ __global__ __launch_bounds__(256) void build_bricks_kernel(const uint32_t *__res
   const uint32_t e = blockIdx.x, xg = e >> 10, yg = (e >> 5) & 31u, zg = e & 31u, tid = threadIdx.x;
   uint32_t v = 0, code = 1u, m = 0;
   bool ok = true;
+  int band = -18;                                     // exponent of this position's band (see tree_lookup_pow2 BRICK): at least 2^-18
   for (int l = 1; l <= 5 && code == 1u; l++) {
     const int sh = 5 - l;
+    const int need = brick_band_exp(l, v);            // the decision of this level adds the coordinate to v
+    band = need > band ? need : band;
     brick_node(cells, cells_dwords, ((2u * v + ((xg >> sh) & 1u)) << 2) + (((yg >> sh) & 1u) << 1) + ((zg >> sh) & 1u), v, code);
     m = (uint32_t)l;
-    if (code == 1u && l < 5 && v >= grid_v_bound(l)) ok = false;          // this v feeds the next level's x decision
+    if (code == 1u && l < 5 && v >= grid_v_bound(l)) ok = false;          // this v feeds the next level's x decision (bounds: band <= 2^-11)
   }
   if (!ok && tid == 0) atomicOr(bad, 1u);
+  const uint32_t k = band >= -11 ? 0u : (uint32_t)(-11 - band);           // band 2^-(11 + k) >= 2^band, k in 0..7
   if (code != 1u) {                                   // EMPTY / LEAF within five levels
-    if (code == 2u && v >= (1u << 26) && tid == 0) atomicOr(bad, 1u);
-    if (tid == 0) grid32[e] = (code == 2u ? v << 6 : 0u) | (m << 2) | code;
+    if (code == 2u && v >= (1u << 23) && tid == 0) atomicOr(bad, 1u);
+    if (tid == 0) grid32[e] = (code == 2u ? v << 6 : 0u) | (m << 2) | code | (k << 29);
     return;
   }
   __shared__ uint32_t s6v[12], s6c[12], s7v[144], s7c[144], s_lo7, s_hi7, s_lo8, s_hi8, s_inv;
-  if (tid == 0) { s_lo7 = 31u; s_hi7 = 0u; s_lo8 = 31u; s_hi8 = 0u; s_inv = (v == 0u || v >= (1u << 20)) ? 1u : 0u; }
+  if (tid == 0) { s_lo7 = 31u; s_hi7 = 0u; s_lo8 = 31u; s_hi8 = 0u; s_inv = (v == 0u || v >= (1u << 17)) ? 1u : 0u; }
   __syncthreads();
   if (tid < 12) {                                     // the level-6 nodes: (a + b) x y x z
     uint32_t w, c;
@@ -564,7 +569,7 @@ __global__ __launch_bounds__(256) void build_bricks_kernel(const uint32_t *__res
   if (tid == 0) {
     const bool shared7 = s_lo7 == 31u || s_lo7 == s_hi7, shared8 = s_lo8 == 31u || s_lo8 == s_hi8;     // (31: no PARENT on that level)
     const uint32_t e7 = s_lo7 == 31u ? 0u : s_lo7, e8 = s_lo8 == 31u ? 0u : s_lo8;
-    grid32[e] = (s_inv == 0u && shared7 && shared8) ? (1u | (e7 << 2) | (e8 << 7) | (v << 12)) : (1u | (31u << 2) | ((v & 0xFFFFFu) << 12));
+    grid32[e] = (s_inv == 0u && shared7 && shared8) ? (1u | (e7 << 2) | (e8 << 7) | (v << 12) | (k << 29)) : (1u | (31u << 2) | ((v & 0x1FFFFu) << 12) | (k << 29));
   }
 }
 
@@ -622,6 +627,28 @@ __global__ __launch_bounds__(256) void selftest_kernel(int which, unsigned long 
                           (__float_as_uint(f.ny) == __float_as_uint(l.ny) || (f.ny != f.ny && l.ny != l.ny)) &&
                           (__float_as_uint(f.nz) == __float_as_uint(l.nz) || (f.nz != f.nz && l.nz != l.nz)) && f.ff == l.ff;
         bad += same ? 0u : 1u;
+      }
+      continue;
+    }
+    if (which == 15 || which == 16) {
+      // the per-position bands of the bricks' level-5 table: outside 2^max(-18, 5 - l + floor(log2 v) - 23) around the integers of
+      // 32 c the x decision of level l with cell index v is the coordinate's binary digit and never 2v + 2 — every coordinate x
+      // every level x every cell index below the level's bound, each with ITS band (mode 7 checks one band for all).  16: the
+      // harness — with half the band the claim must fail.
+      if (!(x >= 0.0f && x < 1.0f)) continue;
+      const float tg = x * 32.0f, dist = __builtin_fabsf(tg - __builtin_rintf(tg));
+      const uint32_t xg = (uint32_t)tg;
+      for (int l = 1; l <= 5; l++) {
+        const float f = l == 1 ? x : f_fract_nonneg(x * (float)(1 << (l - 1)));
+        const uint32_t digit = (xg >> (5 - l)) & 1u;
+        const uint32_t vmax = l == 1 ? 1u : grid_v_bound(l - 1);
+        for (uint32_t v = 0; v < vmax; v++) {
+          int be = brick_band_exp(l, v); be = be < -18 ? -18 : be;
+          const float band = __builtin_ldexpf(1.0f, which == 15 ? be : be - 1);
+          if (!(dist > band)) continue;
+          const float fv = (float)v, q = (fv + f) - fv;
+          bad += ((q > 0.5f ? 1u : 0u) != digit || q == 1.0f) ? 1u : 0u;
+        }
       }
       continue;
     }
@@ -1669,7 +1696,7 @@ int tdt_debug_wave_ends(tdt_ctx *ctx, uint64_t *out, int n) {
 /* Exhaustive self-test of the kernels' short correctly-rounded rcp / sqrt / rsq forms against the
  * IEEE expressions on all 2^32 inputs; *mismatches must come back 0 (which: 0 rcp, 1 sqrt, 2 rsq). */
 int tdt_selftest(tdt_ctx *ctx, int which, uint64_t *mismatches) {
-  if (!ctx || !mismatches || which < 0 || which > 14) return TDT_ERR_INVALID_VALUE;
+  if (!ctx || !mismatches || which < 0 || which > 16) return TDT_ERR_INVALID_VALUE;
   TDT_HIP(ctx, hipSetDevice(ctx->device));
   if (!ctx->counters) TDT_HIP(ctx, hipMalloc((void **)&ctx->counters, (32 + 16384 + 256) * sizeof(unsigned long long)));
   TDT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));

@@ -447,10 +447,17 @@ constexpr int kMemoFirst = 3;       // levels 1..3 = cells 0..72 at most: always
 // walk; the level-5 table entry carries the level-6 cell index (the level-6 decision uses it as it is) and the exponents e7, e8
 // for the decisions of levels 7 and 8 (31: the cells below this position do not share one — the wave walks).  A traversal
 // step is then one LDS read and one 2-byte load instead of a table read, three memo compares and up to three dependent L2
-// round trips.  Table entries (32 bits): PARENT 1 | e7 << 2 | e8 << 7 | v << 12; EMPTY / LEAF value << 6 | levels << 2 | code.
-// Brick entries (16 bits): levels << 2 | code, and a LEAF's value << 6 (a material index >= 1024 below a position: it walks).
+// round trips.  Table entries (32 bits): PARENT 1 | e7 << 2 | e8 << 7 | v << 12 | k << 29; EMPTY / LEAF code | levels << 2 |
+// value << 6 | k << 29.  Brick entries (16 bits): levels << 2 | code, and a LEAF's value << 6 (a material index >= 1024 below a position:
+// it walks).  k: the position's own band — the x decisions of its five levels are the coordinate's digits unless 32 c is within
+// 2^-(11 + k) of an integer, where 2^-(11 + k) >= 2^(5 - l) ulp(v_l + f) for the cell index v_l each level l really uses (the
+// table-wide 2^-11 of the 16-bit tables assumes the largest index the bounds allow, 8191 at level 5; a sparse tree's top cells
+// have indices in the hundreds, and every wave that walks costs a handful of dependent L2 round trips: 4K/256^3 -20 %).
+// Checked for every coordinate x level x cell index below the bounds, each with its own band (tdt_selftest 15).
 constexpr uint32_t kBrickEntries = 27u * 64u;         // per level-5 position (2 bytes each; 32768 positions: 113 MB of address space, touched where the tree is)
 constexpr uint32_t kBrickLdsCells = 1024u;            // BRICK builds keep a small node table (the walk of waves with a lane in a band starts in it)
+// exponent B of the band (in units of 2^L c, L = 5) a level-l decision with cell index v needs: 2^(5 - l) ulp(v + f), ulp = 2^(floor(log2 v) - 23)
+TDT_DEV int brick_band_exp(int l, uint32_t v) { return (v == 0u ? -40 : (31 - (int)__builtin_clz(v)) + 5 - l - 23); }
 // fl(v + f) - v for any integer v in [2^e, 2^(e+1)), e <= 21
 TDT_DEV float brick_q(uint32_t e, float f) { const float V = __uint_as_float((127u + e) << 23); return (V + f) - V; }
 template <bool COUNT, int CL, int DEPTH, bool RESIDENT, bool SAFEV, bool FULL = false, bool BRICK = false>
@@ -491,12 +498,14 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
     const uint32_t e = (xg << 10) | ((Yi >> (DEPTH - 5)) << 5) | (Zi >> (DEPTH - 5));
     const uint32_t g = ns.grid32[e];
     const bool parent = (g & 3u) == 1u;
-    const bool ok = __builtin_fabsf(tg - __builtin_rintf(tg)) > Grid<5>::kBand && !(parent && ((g >> 2) & 31u) == 31u);
+    // the band of THIS position: 2^-(11 + k), k from the cell indices its five levels really add the coordinate to (see brick_band_k)
+    const float band = __uint_as_float((116u - (g >> 29)) << 23);
+    const bool ok = __builtin_fabsf(tg - __builtin_rintf(tg)) > band && !(parent && ((g >> 2) & 31u) == 31u);
     if (__builtin_expect(__ballot(!ok) == 0ull, 1)) {
-      uint32_t ent = g, xd = xg << 3;                 // what the descent ends on; its eight x digits (the top `levels` count)
+      uint32_t ent = g & 0x1FFFFFFFu, xd = xg << 3;   // what the descent ends on (a non-PARENT table entry IS a brick entry below its k); its eight x digits (the top `levels` count)
       if (parent) {
         const float f6 = f_fract_nonneg(tg), f7 = f_fract_nonneg(fx0 * 64.0f), f8 = f_fract_nonneg(fx0 * 128.0f);
-        const float fv = (float)(g >> 12);
+        const float fv = (float)((g >> 12) & 0x1FFFFu);
         const float q6 = (fv + f6) - fv, q7 = brick_q((g >> 2) & 31u, f7), q8 = brick_q((g >> 7) & 31u, f8);
         const uint32_t a6 = q6 > 0.5f ? 1u : 0u, b6 = q6 == 1.0f ? 1u : 0u, a7 = q7 > 0.5f ? 1u : 0u, b7 = q7 == 1.0f ? 1u : 0u,
                        a8 = q8 > 0.5f ? 1u : 0u, b8 = q8 == 1.0f ? 1u : 0u;

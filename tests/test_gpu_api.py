@@ -355,3 +355,5 @@ def test_short_rounding_forms_exhaustively():
         assert ctx.selftest(12) > 0
         assert ctx.selftest(13) == 0     # fl(v + f) - v is a function of floor(log2 v) and f (the bricks of depth-8 trees)
         assert ctx.selftest(14) > 0
+        assert ctx.selftest(15) == 0     # ... and their level-5 table's bands, one per cell index
+        assert ctx.selftest(16) > 0
