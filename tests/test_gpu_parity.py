@@ -99,7 +99,8 @@ def test_relocated_top_cells_disable_the_jump_table(oracle):
         r.close()
 
 
-@pytest.mark.parametrize("cfg,case", [(3, "wide_materials"), (5, "wide_materials"), (3, "scattered_cells"), (5, "scattered_cells"), (3, "zero_child")])
+@pytest.mark.parametrize("cfg,case", [(3, "wide_materials"), (5, "wide_materials"), (3, "scattered_cells"), (5, "scattered_cells"), (3, "zero_child"),
+                                      (2, "wide_materials")])   # (the whole-depth table of small trees: no table at all, the 4-level form runs)
 def test_positions_whose_bricks_cannot_be_built_walk(oracle, cfg, case):
     """The bricks of depth-8 / 9 trees (build_bricks_kernel) mark a level-5 position whose sub-tree they cannot represent — a
     material index that does not fit the entry, level-7 / level-8 cells that do not share floor(log2(index)), a PARENT that
