@@ -510,7 +510,7 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
         const uint32_t a6 = q6 > 0.5f ? 1u : 0u, b6 = q6 == 1.0f ? 1u : 0u, a7 = q7 > 0.5f ? 1u : 0u, b7 = q7 == 1.0f ? 1u : 0u,
                        a8 = q8 > 0.5f ? 1u : 0u, b8 = q8 == 1.0f ? 1u : 0u;
         const uint32_t ci = ((a6 + b6) * 3u + (a7 + b7)) * 3u + (a8 + b8);
-        const uint32_t bi = e * kBrickEntries + ((ci << 6) | (((Yi >> (DEPTH - 8)) & 7u) << 3) | ((Zi >> (DEPTH - 8)) & 7u));
+        const uint32_t bi = ((__umul24(e, 27u) + ci) << 6) | (((Yi >> (DEPTH - 8)) & 7u) << 3) | ((Zi >> (DEPTH - 8)) & 7u);      // e * kBrickEntries + ci * 64 + y3 * 8 + z3
         ent = DEPTH == 8 ? (uint32_t)static_cast<const uint16_t *>(ns.bricks)[bi] : static_cast<const uint32_t *>(ns.bricks)[bi];
         xd |= ((a6 & ~b6) << 2) | ((a7 & ~b7) << 1) | (a8 & ~b8);
       }
