@@ -1111,9 +1111,13 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
         if (ctx->bricks_bytes < need) {
           if (ctx->bricks) (void)hipFree(ctx->bricks);
           ctx->bricks = nullptr; ctx->bricks_bytes = 0; ctx->brick_of = nullptr;
-          TDT_HIP(ctx, hipMalloc(&ctx->bricks, need));
-          ctx->bricks_bytes = need;
+          if (hipMalloc(&ctx->bricks, need) != hipSuccess) {      // (a device that cannot spare the address space: the levels are walked)
+            (void)hipGetLastError();
+            ctx->bricks = nullptr; ctx->no_bricks = true;
+          } else ctx->bricks_bytes = need;
         }
+      }
+      if (!ctx->no_bricks && (ctx->brick_of != cb || ctx->brick_version != cb->version || ctx->brick_depth != P.max_depth)) {
         uint32_t *bad = ctx->brick_grid + ((size_t)1 << 15);
         TDT_HIP(ctx, hipMemsetAsync(bad, 0, sizeof(uint32_t), ctx->stream));
         if (P.max_depth == 9) hipLaunchKernelGGL(tdt::build_bricks_kernel<uint32_t>, dim3(1u << 15), dim3(256), 0, ctx->stream, P.cells, P.cells_dwords, ctx->brick_grid, static_cast<uint32_t *>(ctx->bricks), bad);
@@ -1124,7 +1128,7 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
         TDT_HIP(ctx, hipStreamSynchronize(ctx->stream));    // once per cells buffer (version), not per frame
         ctx->brick_of = cb; ctx->brick_version = cb->version; ctx->brick_depth = P.max_depth; ctx->brick_ok = flag == 0;
       }
-      brick = ctx->brick_ok;
+      brick = !ctx->no_bricks && ctx->brick_ok;
       if (brick) {
         P.brick_grid = ctx->brick_grid; P.bricks = ctx->bricks;
         if (P.lds_nodes > tdt::kBrickLdsCells * 8u) P.lds_nodes = tdt::kBrickLdsCells * 8u;      // (the BRICK builds' LDS node table)

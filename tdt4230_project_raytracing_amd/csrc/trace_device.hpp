@@ -500,8 +500,8 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
     const bool parent = (g & 3u) == 1u;
     // the band of THIS position: 2^-(11 + k), k from the cell indices its five levels really add the coordinate to (see brick_band_k)
     const float band = __uint_as_float((116u - (g >> 29)) << 23);
-    const bool ok = __builtin_fabsf(tg - __builtin_rintf(tg)) > band && !(parent && ((g >> 2) & 31u) == 31u);
-    if (__builtin_expect(__ballot(!ok) == 0ull, 1)) {
+    // (two ballots: one of the AND-ed condition goes through a 0 / 1 register and a second compare)
+    if (__builtin_expect((__ballot(!(__builtin_fabsf(tg - __builtin_rintf(tg)) > band)) | __ballot((g & 0x7Fu) == 0x7Du)) == 0ull, 1)) {      // 0x7D: PARENT, e7 = 31
       uint32_t ent = g & 0x1FFFFFFFu, xd = xg << 3;   // what the descent ends on (a non-PARENT table entry IS a brick entry below its k); its eight x digits (the top `levels` count)
       if (parent) {
         const float f6 = f_fract_nonneg(tg), f7 = f_fract_nonneg(fx0 * 64.0f), f8 = f_fract_nonneg(fx0 * 128.0f);
