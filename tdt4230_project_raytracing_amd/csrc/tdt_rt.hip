@@ -488,22 +488,22 @@ __global__ __launch_bounds__(256) void build_full_grid_kernel(const uint32_t *__
 
 // The bricks of BRICK builds (see tree_lookup_pow2): one block per level-5 position e = x5 << 10 | y5 << 5 | z5.  Every thread walks
 // the five levels above it as treeLookup would (digits of e; the bands keep the lanes away from coordinates where that is not
-// what the reference does); a position that holds a PARENT gets its 27 x 64 entries by walking on, once per decision sequence,
-// reading the real nodes (past the end of the buffer: zeros) — the 12 level-6 nodes and up to 144 level-7 nodes through LDS.
-// grid32[e] = what tree_lookup_pow2 decodes; e7 = 31 when the level-7 / level-8 cells reachable from here do not share
-// floor(log2(index)), an index is 0 or does not fit (level-6 cell >= 2^17), or a LEAF value does not fit the entry: waves that
-// meet such a position walk.
-// *bad: a PARENT above level 5 at or beyond grid_v_bound (the table's own claim does not hold: no BRICK build for this tree).
+// what the reference does); a position that holds a PARENT gets its 27 x 64 (depth 8) or 81 x 256 (depth 9) entries by walking
+// on, once per decision sequence, reading the real nodes (past the end of the buffer: zeros) — the nodes of all brick levels but
+// the last through LDS.  grid32[e] = what tree_lookup_pow2 decodes; the first exponent is 31 when the cells of some level
+// reachable from here do not share floor(log2(index)), an index is 0 or >= 2^22, or a LEAF value does not fit the entry: waves
+// that meet such a position walk.  *bad: a PARENT above level 5 at or beyond grid_v_bound (the table's own claim does not hold:
+// no BRICK build for this tree).
 __device__ __forceinline__ void brick_node(const uint32_t *__restrict__ cells, uint32_t cells_dwords, uint32_t idx, uint32_t &value, uint32_t &code) {
   idx &= 0x1FFFFFFFu;
   uint32_t type = 0; value = 0;
   if (2u * idx + 1u < cells_dwords) { value = cells[2u * idx]; type = cells[2u * idx + 1u]; }     // reads past the end are 0 (robust access)
   code = (type == 0u) ? 0u : (type == 2u ? 2u : 1u);
 }
-template <typename Entry>                              // uint16_t: depth-8 trees; uint32_t: depth 9 (a level-8 PARENT's value goes with the entry: level 9 is walked)
+template <int BL>                                     // levels a brick covers: 3 (depth 8) or 4 (depth 9)
 __global__ __launch_bounds__(256) void build_bricks_kernel(const uint32_t *__restrict__ cells, uint32_t cells_dwords, uint32_t *__restrict__ grid32,
-                                                           Entry *__restrict__ bricks, uint32_t *__restrict__ bad) {
-  constexpr bool kWide = sizeof(Entry) == 4;
+                                                           uint16_t *__restrict__ bricks, uint32_t *__restrict__ bad) {
+  constexpr uint32_t kEntries = brick_entries(5 + BL), kStored = BL == 3 ? 12u + 144u : 12u + 144u + 1728u;   // nodes of the levels kept in LDS
   const uint32_t e = blockIdx.x, xg = e >> 10, yg = (e >> 5) & 31u, zg = e & 31u, tid = threadIdx.x;
   uint32_t v = 0, code = 1u, m = 0;
   bool ok = true;
@@ -523,53 +523,72 @@ __global__ __launch_bounds__(256) void build_bricks_kernel(const uint32_t *__res
     if (tid == 0) grid32[e] = (code == 2u ? v << 6 : 0u) | (m << 2) | code | (k << 29);
     return;
   }
-  __shared__ uint32_t s6v[12], s6c[12], s7v[144], s7c[144], s_lo7, s_hi7, s_lo8, s_hi8, s_inv;
-  if (tid == 0) { s_lo7 = 31u; s_hi7 = 0u; s_lo8 = 31u; s_hi8 = 0u; s_inv = (v == 0u || v >= (1u << 17)) ? 1u : 0u; }
+  // PARENT: v is the level-6 cell.  s_v / s_c: the nodes of level 6 (12: (a + b) x y x z), level 7 (12 below each), level 8 (depth 9)
+  __shared__ uint32_t s_v[kStored], s_c[kStored], s_lo[4], s_hi[4], s_inv;
+  if (tid < 4) { s_lo[tid] = 31u; s_hi[tid] = 0u; }
+  if (tid == 0) s_inv = 0u;
   __syncthreads();
-  if (tid < 12) {                                     // the level-6 nodes: (a + b) x y x z
+  auto note = [&](int level_j, uint32_t w) {          // w: a cell index the decision of brick level level_j adds the coordinate to
+    if (w == 0u || w >= (1u << 22)) atomicOr(&s_inv, 1u);
+    else { const uint32_t ex = 31u - (uint32_t)__builtin_clz(w); atomicMin(&s_lo[level_j], ex); atomicMax(&s_hi[level_j], ex); }
+  };
+  if (tid == 0) note(0, v);
+  if (tid < 12) {
     uint32_t w, c;
     brick_node(cells, cells_dwords, ((2u * v + (tid >> 2)) << 2) + (tid & 3u), w, c);
-    s6v[tid] = w; s6c[tid] = c;
-    if (c == 1u) {
-      if (w == 0u || w >= (1u << 22)) atomicOr(&s_inv, 1u);
-      else { const uint32_t ex = 31u - (uint32_t)__builtin_clz(w); atomicMin(&s_lo7, ex); atomicMax(&s_hi7, ex); }
-    }
+    s_v[tid] = w; s_c[tid] = c;
+    if (c == 1u) note(1, w);
   }
   __syncthreads();
-  if (tid < 144) {                                    // the level-7 nodes below each level-6 PARENT
-    const uint32_t i6 = tid / 12u, i7 = tid % 12u;
+  for (uint32_t i = tid; i < 144u; i += 256u) {
+    const uint32_t up = i / 12u, sub = i % 12u;
     uint32_t w = 0, c = 0;
-    if (s6c[i6] == 1u) {
-      brick_node(cells, cells_dwords, ((2u * s6v[i6] + (i7 >> 2)) << 2) + (i7 & 3u), w, c);
-      if (c == 1u) {
-        if (w == 0u || w >= (1u << 22)) atomicOr(&s_inv, 1u);
-        else { const uint32_t ex = 31u - (uint32_t)__builtin_clz(w); atomicMin(&s_lo8, ex); atomicMax(&s_hi8, ex); }
-      }
+    if (s_c[up] == 1u) {
+      brick_node(cells, cells_dwords, ((2u * s_v[up] + (sub >> 2)) << 2) + (sub & 3u), w, c);
+      if (c == 1u) note(2, w);
     }
-    s7v[tid] = w; s7c[tid] = c;
+    s_v[12u + i] = w; s_c[12u + i] = c;
   }
   __syncthreads();
-  for (uint32_t s = tid; s < kBrickEntries; s += 256u) {
-    const uint32_t ci = s >> 6, yz = s & 63u, c6 = ci / 9u, c7 = (ci / 3u) % 3u, c8 = ci % 3u;
-    const uint32_t i6 = (c6 << 2) | (((yz >> 5) & 1u) << 1) | ((yz >> 2) & 1u);
-    uint32_t val = s6v[i6], cd = s6c[i6], mm = 6u;
-    if (cd == 1u) {
-      const uint32_t i7 = (c7 << 2) | (((yz >> 4) & 1u) << 1) | ((yz >> 1) & 1u);
-      val = s7v[i6 * 12u + i7]; cd = s7c[i6 * 12u + i7]; mm = 7u;
-      if (cd == 1u) {
-        brick_node(cells, cells_dwords, ((2u * val + c8) << 2) + (((yz >> 3) & 1u) << 1) + (yz & 1u), val, cd);
-        mm = 8u;
+  if (BL == 4) {
+    for (uint32_t i = tid; i < 1728u; i += 256u) {
+      const uint32_t up = i / 12u, sub = i % 12u;
+      uint32_t w = 0, c = 0;
+      if (s_c[12u + up] == 1u) {
+        brick_node(cells, cells_dwords, ((2u * s_v[12u + up] + (sub >> 2)) << 2) + (sub & 3u), w, c);
+        if (c == 1u) note(3, w);
       }
+      s_v[156u + i] = w; s_c[156u + i] = c;
     }
-    if (cd == 2u && val >= (kWide ? (1u << 26) : 1024u)) atomicOr(&s_inv, 1u);
-    if (kWide && cd == 1u && (val == 0u || val >= (1u << 22))) atomicOr(&s_inv, 1u);
-    bricks[(size_t)e * kBrickEntries + s] = (Entry)(((cd == 2u || (kWide && cd == 1u)) ? val << 6 : 0u) | (mm << 2) | cd);
+    __syncthreads();
+  }
+  for (uint32_t s = tid; s < kEntries; s += 256u) {
+    const uint32_t ci = s >> (2 * BL), yb = (s >> BL) & ((1u << BL) - 1u), zb = s & ((1u << BL) - 1u);
+    uint32_t val = 0, cd = 1u, mm = 5u, at = 0u, base = 0u, count = 12u, div = BL == 3 ? 9u : 27u;
+    uint32_t prev_v = v;
+    for (int j = 0; j < BL && cd == 1u; j++) {        // level 6 + j
+      const uint32_t c = (ci / div) % 3u, y = (yb >> (BL - 1 - j)) & 1u, z = (zb >> (BL - 1 - j)) & 1u, sub = (c << 2) | (y << 1) | z;
+      if (j < BL - 1) {                               // a stored level
+        at = at * 12u + sub;
+        val = s_v[base + at]; cd = s_c[base + at];
+        base += count; count *= 12u;
+      } else {
+        brick_node(cells, cells_dwords, ((2u * prev_v + c) << 2) + (y << 1) + z, val, cd);
+      }
+      prev_v = val; mm = 6u + (uint32_t)j; div /= 3u;
+    }
+    if (cd == 2u && val >= 1024u) atomicOr(&s_inv, 1u);
+    bricks[(size_t)e * kEntries + s] = (uint16_t)((cd == 2u ? val << 6 : 0u) | (mm << 2) | cd);
   }
   __syncthreads();
   if (tid == 0) {
-    const bool shared7 = s_lo7 == 31u || s_lo7 == s_hi7, shared8 = s_lo8 == 31u || s_lo8 == s_hi8;     // (31: no PARENT on that level)
-    const uint32_t e7 = s_lo7 == 31u ? 0u : s_lo7, e8 = s_lo8 == 31u ? 0u : s_lo8;
-    grid32[e] = (s_inv == 0u && shared7 && shared8) ? (1u | (e7 << 2) | (e8 << 7) | (v << 12) | (k << 29)) : (1u | (31u << 2) | ((v & 0x1FFFFu) << 12) | (k << 29));
+    bool shared = s_inv == 0u;
+    uint32_t word = 1u | (k << 29);
+    for (int j = 0; j < BL; j++) {
+      shared = shared && (s_lo[j] == 31u || s_lo[j] == s_hi[j]);          // (31: no PARENT leads to that level)
+      word |= (s_lo[j] == 31u ? 0u : s_lo[j]) << (2 + 5 * j);
+    }
+    grid32[e] = shared ? word : (1u | (31u << 2) | (k << 29));
   }
 }
 
@@ -1106,7 +1125,7 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     if (mode != 2 && !counts_out && pow2 && safev && !resident && !ctx->no_specialise && !ctx->no_bricks && (P.max_depth == 8 || P.max_depth == 9)) {
       const tdt_buffer *cb = ctx->ssbo[TDT_SLOT_CELLS];
       if (ctx->brick_of != cb || ctx->brick_version != cb->version || ctx->brick_depth != P.max_depth) {
-        const size_t need = ((size_t)1 << 15) * tdt::kBrickEntries * (P.max_depth == 9 ? sizeof(uint32_t) : sizeof(uint16_t));
+        const size_t need = ((size_t)1 << 15) * tdt::brick_entries(P.max_depth) * sizeof(uint16_t);
         if (!ctx->brick_grid) TDT_HIP(ctx, hipMalloc((void **)&ctx->brick_grid, ((size_t)1 << 15) * sizeof(uint32_t) + sizeof(uint32_t)));
         if (ctx->bricks_bytes < need) {
           if (ctx->bricks) (void)hipFree(ctx->bricks);
@@ -1120,8 +1139,8 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
       if (!ctx->no_bricks && (ctx->brick_of != cb || ctx->brick_version != cb->version || ctx->brick_depth != P.max_depth)) {
         uint32_t *bad = ctx->brick_grid + ((size_t)1 << 15);
         TDT_HIP(ctx, hipMemsetAsync(bad, 0, sizeof(uint32_t), ctx->stream));
-        if (P.max_depth == 9) hipLaunchKernelGGL(tdt::build_bricks_kernel<uint32_t>, dim3(1u << 15), dim3(256), 0, ctx->stream, P.cells, P.cells_dwords, ctx->brick_grid, static_cast<uint32_t *>(ctx->bricks), bad);
-        else hipLaunchKernelGGL(tdt::build_bricks_kernel<uint16_t>, dim3(1u << 15), dim3(256), 0, ctx->stream, P.cells, P.cells_dwords, ctx->brick_grid, static_cast<uint16_t *>(ctx->bricks), bad);
+        if (P.max_depth == 9) hipLaunchKernelGGL(tdt::build_bricks_kernel<4>, dim3(1u << 15), dim3(256), 0, ctx->stream, P.cells, P.cells_dwords, ctx->brick_grid, static_cast<uint16_t *>(ctx->bricks), bad);
+        else hipLaunchKernelGGL(tdt::build_bricks_kernel<3>, dim3(1u << 15), dim3(256), 0, ctx->stream, P.cells, P.cells_dwords, ctx->brick_grid, static_cast<uint16_t *>(ctx->bricks), bad);
         TDT_HIP(ctx, hipGetLastError());
         uint32_t flag = 1;
         TDT_HIP(ctx, hipMemcpyAsync(&flag, bad, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));

@@ -180,7 +180,7 @@ struct NodeSource {
   const void *grid;                                   // top-level jump table (Grid<GL>::Entry[], see build_top_grid), or unusable when !grid_ok
   bool grid_ok; float grid_band;                      // grid_band = kGridBand, or 2 when the table is unusable
   const uint16_t *full;                               // FULL builds: the whole-depth table in global memory (see tree_lookup_pow2)
-  const uint32_t *grid32; const void *bricks;         // BRICK builds: the 5-level table with brick headers (LDS) and the bricks (global memory: 16-bit entries for depth 8, 32-bit for depth 9)
+  const uint32_t *grid32; const void *bricks;         // BRICK builds: the 5-level table with brick headers (LDS) and the bricks (global memory, 16-bit entries)
   __amdgpu_buffer_rsrc_t cells;                       // raw buffer over the cells payload (8-byte granules)
 };
 
@@ -435,26 +435,27 @@ constexpr int kMemoFirst = 3;       // levels 1..3 = cells 0..72 at most: always
 // read through L2) holds what the whole descent ends on, so a traversal step does ONE load instead of a table read plus two
 // more levels; the bands are those of the 5-level table (cell indices of a resident tree stay below 8192: 2^-11 around the
 // integers of 2^depth c), and a wave with a lane inside one walks all levels from the LDS node table.
-// BRICK (round 2; depth-8 trees that are NOT LDS-resident, every PARENT value < 2^22): levels 6-8 in ONE load as well.  Below
-// level 5 cell indices are large and the x decision  a = fl(v + f) - v > 0.5, b = ... == 1  is far from the coordinate's binary
-// digit (v ~ 2^20: ulp(v + f) = 2^-3), so a table indexed by position would be wrong for a tenth of all coordinates.  But for
-// an integer v < 2^22 the sum v + f is rounded on a grid of 2^(e-23), e = floor(log2 v), that v itself lies on, with ties
-// that do not depend on v: fl(v + f) - v is a function of e and f alone (checked for every f in [0,1) x every e x the ends
-// and the middle of its binade: tdt_selftest 13).  And the cells of one level below one level-5 position are neighbours in the
-// breadth-first array, so they share e.  Hence a "brick" per level-5 position, indexed not by position but by DECISION
-// sequence — (a + b) of levels 6, 7, 8 (27 combinations) x the three y and three z digits (64) — holds exactly what the
-// reference's walk ends on, 2v + 2 jumps into the neighbour cell included, because build_bricks_kernel fills it by doing that
-// walk; the level-5 table entry carries the level-6 cell index (the level-6 decision uses it as it is) and the exponents e7, e8
-// for the decisions of levels 7 and 8 (31: the cells below this position do not share one — the wave walks).  A traversal
-// step is then one LDS read and one 2-byte load instead of a table read, three memo compares and up to three dependent L2
-// round trips.  Table entries (32 bits): PARENT 1 | e7 << 2 | e8 << 7 | v << 12 | k << 29; EMPTY / LEAF code | levels << 2 |
-// value << 6 | k << 29.  Brick entries (16 bits): levels << 2 | code, and a LEAF's value << 6 (a material index >= 1024 below a position:
-// it walks).  k: the position's own band — the x decisions of its five levels are the coordinate's digits unless 32 c is within
-// 2^-(11 + k) of an integer, where 2^-(11 + k) >= 2^(5 - l) ulp(v_l + f) for the cell index v_l each level l really uses (the
-// table-wide 2^-11 of the 16-bit tables assumes the largest index the bounds allow, 8191 at level 5; a sparse tree's top cells
-// have indices in the hundreds, and every wave that walks costs a handful of dependent L2 round trips: 4K/256^3 -20 %).
-// Checked for every coordinate x level x cell index below the bounds, each with its own band (tdt_selftest 15).
-constexpr uint32_t kBrickEntries = 27u * 64u;         // per level-5 position (2 bytes each; 32768 positions: 113 MB of address space, touched where the tree is)
+// BRICK (round 2; depth-8 and depth-9 trees that are NOT LDS-resident, every PARENT value < 2^22): the levels below 5 in ONE load
+// as well.  Below level 5 cell indices are large and the x decision  a = fl(v + f) - v > 0.5, b = ... == 1  is far from the
+// coordinate's binary digit (v ~ 2^20: ulp(v + f) = 2^-3), so a table indexed by position would be wrong for a tenth of all
+// coordinates.  But for an integer v < 2^22 the sum v + f is rounded on a grid of 2^(e-23), e = floor(log2 v), that v itself
+// lies on, with ties that do not depend on v: fl(v + f) - v is a function of e and f alone (checked for every f in [0,1) x every
+// e x the ends and the middle of its binade: tdt_selftest 13).  And the cells of one level below one level-5 position are
+// neighbours in the breadth-first array, so they share e.  Hence a "brick" per level-5 position, indexed not by position but
+// by DECISION sequence — (a + b) of levels 6, 7, 8 (and 9: 27 or 81 combinations) x the y and z digits of those levels (64 or 256)
+// — holds exactly what the reference's walk ends on, 2v + 2 jumps into the neighbour cell included, because
+// build_bricks_kernel fills it by doing that walk; the level-5 table entry carries the exponents of the cell indices the
+// decisions of levels 6.. add the coordinate to (31: the cells of a level below this position do not share one — the wave
+// walks).  A traversal step is then one LDS read and one 2-byte load instead of a table read, three or four memo compares and
+// as many dependent L2 round trips.  Table entries (32 bits): PARENT 1 | e6 << 2 | e7 << 7 | e8 << 12 | e9 << 17 | k << 29; EMPTY /
+// LEAF code | levels << 2 | value << 6 | k << 29.  Brick entries (16 bits): levels << 2 | code, and a LEAF's value << 6 (a material
+// index >= 1024 below a position: it walks).  k: the position's own band — the x decisions of its five levels are the
+// coordinate's digits unless 32 c is within 2^-(11 + k) of an integer, where 2^-(11 + k) >= 2^(5 - l) ulp(v_l + f) for the
+// cell index v_l each level l really uses (the table-wide 2^-11 of the 16-bit tables assumes the largest index the bounds allow,
+// 8191 at level 5; a sparse tree's top cells have indices in the hundreds, and every wave that walks costs a handful of
+// dependent L2 round trips: 4K/256^3 -20 %).  Checked for every coordinate x level x cell index below the bounds, each with its
+// own band (tdt_selftest 15).
+__host__ __device__ constexpr uint32_t brick_entries(int depth) { return depth == 9 ? 81u * 256u : 27u * 64u; }   // per level-5 position, 2 bytes each; 32768 positions: 113 MB / 1.36 GB of address space, touched where the tree is
 constexpr uint32_t kBrickLdsCells = 1024u;            // BRICK builds keep a small node table (the walk of waves with a lane in a band starts in it)
 // exponent B of the band (in units of 2^L c, L = 5) a level-l decision with cell index v needs: 2^(5 - l) ulp(v + f), ulp = 2^(floor(log2 v) - 23)
 TDT_DEV int brick_band_exp(int l, uint32_t v) { return (v == 0u ? -40 : (31 - (int)__builtin_clz(v)) + 5 - l - 23); }
@@ -476,7 +477,7 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
   const float fx0 = fx;
   bool jumped = false;
   constexpr int kTableLevels = RESIDENT ? 4 : 5;                      // (see Grid<GL>)
-  constexpr int kGridLevels = FULL ? DEPTH : (BRICK ? 8 : kTableLevels);   // levels the jump covers
+  constexpr int kGridLevels = FULL ? DEPTH : kTableLevels;            // levels the jump covers (BRICK builds: never continue after their jump)
   if constexpr (FULL && !COUNT) {
     const float tg = fx0 * (float)(1 << DEPTH);       // exact
     const bool safe = __builtin_fabsf(tg - __builtin_rintf(tg)) > ns.grid_band;
@@ -493,41 +494,37 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
     }
   } else if constexpr (BRICK && !COUNT) {
     static_assert(!BRICK || ((DEPTH == 8 || DEPTH == 9) && !RESIDENT && SAFEV), "bricks: depth-8 / depth-9 trees outside the LDS table");
+    constexpr int BL = DEPTH - 5;                     // levels a brick covers: all of them below the table
     const float tg = fx0 * 32.0f;                     // exact
     const uint32_t xg = (uint32_t)tg;
-    const uint32_t e = (xg << 10) | ((Yi >> (DEPTH - 5)) << 5) | (Zi >> (DEPTH - 5));
+    const uint32_t e = (xg << 10) | ((Yi >> BL) << 5) | (Zi >> BL);
     const uint32_t g = ns.grid32[e];
-    const bool parent = (g & 3u) == 1u;
-    // the band of THIS position: 2^-(11 + k), k from the cell indices its five levels really add the coordinate to (see brick_band_k)
+    // the band of THIS position: 2^-(11 + k), k from the cell indices its five levels really add the coordinate to (brick_band_exp)
     const float band = __uint_as_float((116u - (g >> 29)) << 23);
     // (two ballots: one of the AND-ed condition goes through a 0 / 1 register and a second compare)
-    if (__builtin_expect((__ballot(!(__builtin_fabsf(tg - __builtin_rintf(tg)) > band)) | __ballot((g & 0x7Fu) == 0x7Du)) == 0ull, 1)) {      // 0x7D: PARENT, e7 = 31
-      uint32_t ent = g & 0x1FFFFFFFu, xd = xg << 3;   // what the descent ends on (a non-PARENT table entry IS a brick entry below its k); its eight x digits (the top `levels` count)
-      if (parent) {
-        const float f6 = f_fract_nonneg(tg), f7 = f_fract_nonneg(fx0 * 64.0f), f8 = f_fract_nonneg(fx0 * 128.0f);
-        const float fv = (float)((g >> 12) & 0x1FFFFu);
-        const float q6 = (fv + f6) - fv, q7 = brick_q((g >> 2) & 31u, f7), q8 = brick_q((g >> 7) & 31u, f8);
-        const uint32_t a6 = q6 > 0.5f ? 1u : 0u, b6 = q6 == 1.0f ? 1u : 0u, a7 = q7 > 0.5f ? 1u : 0u, b7 = q7 == 1.0f ? 1u : 0u,
-                       a8 = q8 > 0.5f ? 1u : 0u, b8 = q8 == 1.0f ? 1u : 0u;
-        const uint32_t ci = ((a6 + b6) * 3u + (a7 + b7)) * 3u + (a8 + b8);
-        const uint32_t bi = ((__umul24(e, 27u) + ci) << 6) | (((Yi >> (DEPTH - 8)) & 7u) << 3) | ((Zi >> (DEPTH - 8)) & 7u);      // e * kBrickEntries + ci * 64 + y3 * 8 + z3
-        ent = DEPTH == 8 ? (uint32_t)static_cast<const uint16_t *>(ns.bricks)[bi] : static_cast<const uint32_t *>(ns.bricks)[bi];
-        xd |= ((a6 & ~b6) << 2) | ((a7 & ~b7) << 1) | (a8 & ~b8);
+    if (__builtin_expect((__ballot(!(__builtin_fabsf(tg - __builtin_rintf(tg)) > band)) | __ballot((g & 0x7Fu) == 0x7Du)) == 0ull, 1)) {      // 0x7D: PARENT, first exponent 31
+      uint32_t ent = g & 0x1FFFFFFFu, xd = xg << BL;  // what the descent ends on (a non-PARENT table entry IS a brick entry below its k); its x digits (the top `levels` count)
+      if ((g & 3u) == 1u) {
+        uint32_t ci = 0u, xlow = 0u;
+#pragma unroll
+        for (int j = 0; j < BL; j++) {                // level 6 + j: its coordinate, the decision for ANY cell index of the exponent the entry names
+          const float f = j == 0 ? f_fract_nonneg(tg) : f_fract_nonneg(fx0 * (float)(32 << j));
+          const float q = brick_q((g >> (2 + 5 * j)) & 31u, f);
+          const uint32_t a = q > 0.5f ? 1u : 0u, b = q == 1.0f ? 1u : 0u;
+          ci = ci * 3u + a + b;
+          xlow = (xlow << 1) | (a & ~b);
+        }
+        constexpr uint32_t kCombos = BL == 3 ? 27u : 81u, kMask = (1u << BL) - 1u;
+        const uint32_t bi = ((__umul24(e, kCombos) + ci) << (2 * BL)) | ((Yi & kMask) << BL) | (Zi & kMask);
+        ent = static_cast<const uint16_t *>(ns.bricks)[bi];
+        xd |= xlow;
       }
-      const uint32_t mg = (ent >> 2) & 15u;
-      if constexpr (DEPTH == 8) {                     // the whole lookup
-        const uint32_t sh = 8u - mg;
-        const float ipd = __uint_as_float((127u - mg) << 23);                 // 2^-levels
-        gx = (float)(xd >> sh) * ipd; gy = (float)(Yi >> sh) * ipd; gz = (float)(Zi >> sh) * ipd;
-        inv_pow_depth = ipd;
-        value = ent >> 6;
-        return (ent & 3u) == 2u;
-      } else {                                        // depth 9: the last level is walked (its PARENT's value came with the entry)
-        v = ent >> 6; code = ent & 3u;
-        qx = (1u << mg) | (xd >> (8u - mg));
-        fx = f_fract_nonneg(fx0 * 256.0f);            // fract(c * 2^8): level 9's coordinate
-        jumped = true;
-      }
+      const uint32_t mg = (ent >> 2) & 15u, sh = (uint32_t)DEPTH - mg;
+      const float ipd = __uint_as_float((127u - mg) << 23);                   // 2^-levels
+      gx = (float)(xd >> sh) * ipd; gy = (float)(Yi >> sh) * ipd; gz = (float)(Zi >> sh) * ipd;
+      inv_pow_depth = ipd;
+      value = ent >> 6;
+      return (ent & 3u) == 2u;
     }
   } else if constexpr (!COUNT && DEPTH >= kTableLevels) {        // the top levels in one step (see build_top_grid)
     const float tg = fx0 * (float)(1 << kGridLevels);  // exact
