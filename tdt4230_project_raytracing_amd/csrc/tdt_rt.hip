@@ -500,10 +500,10 @@ __device__ __forceinline__ void brick_node(const uint32_t *__restrict__ cells, u
   if (2u * idx + 1u < cells_dwords) { value = cells[2u * idx]; type = cells[2u * idx + 1u]; }     // reads past the end are 0 (robust access)
   code = (type == 0u) ? 0u : (type == 2u ? 2u : 1u);
 }
-template <int BL>                                     // levels a brick covers: 3 (depth 8) or 4 (depth 9)
+template <int BL>                                     // levels a brick covers: 3 (depth 8) or 4 (depth 9); 0: no bricks, the table alone (depths 6, 7, 10)
 __global__ __launch_bounds__(256) void build_bricks_kernel(const uint32_t *__restrict__ cells, uint32_t cells_dwords, uint32_t *__restrict__ grid32,
                                                            uint16_t *__restrict__ bricks, uint32_t *__restrict__ bad) {
-  constexpr uint32_t kEntries = brick_entries(5 + BL), kStored = BL == 3 ? 12u + 144u : 12u + 144u + 1728u;   // nodes of the levels kept in LDS
+  constexpr uint32_t kEntries = brick_entries(5 + BL), kStored = BL == 0 ? 1u : (BL == 3 ? 12u + 144u : 12u + 144u + 1728u);   // nodes of the levels kept in LDS
   const uint32_t e = blockIdx.x, xg = e >> 10, yg = (e >> 5) & 31u, zg = e & 31u, tid = threadIdx.x;
   uint32_t v = 0, code = 1u, m = 0;
   bool ok = true;
@@ -521,6 +521,11 @@ __global__ __launch_bounds__(256) void build_bricks_kernel(const uint32_t *__res
   if (code != 1u) {                                   // EMPTY / LEAF within five levels
     if (code == 2u && v >= (1u << 23) && tid == 0) atomicOr(bad, 1u);
     if (tid == 0) grid32[e] = (code == 2u ? v << 6 : 0u) | (m << 2) | code | (k << 29);
+    return;
+  }
+  if (BL == 0) {                                      // no bricks: the entry hands the level-6 cell to the walk
+    if (tid == 0) grid32[e] = 1u | (v << 2) | (k << 29);
+    if (v >= (1u << 22) && tid == 0) atomicOr(bad, 1u);
     return;
   }
   // PARENT: v is the level-6 cell.  s_v / s_c: the nodes of level 6 (12: (a + b) x y x z), level 7 (12 below each), level 8 (depth 9)
@@ -1120,12 +1125,14 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
       full = ctx->full_ok;
       P.full_grid = ctx->full_grid;
     }
-    // depth-8 trees that are not LDS-resident: bricks (tree_lookup_pow2 BRICK), built once per cells buffer
+    // trees of depth 6-10 that are not LDS-resident: the 32-bit level-5 table with per-position bands, and for depth 8 / 9 the bricks
+    // (tree_lookup_pow2 BRICK), built once per cells buffer
     bool brick = false;
-    if (mode != 2 && !counts_out && pow2 && safev && !resident && !ctx->no_specialise && !ctx->no_bricks && (P.max_depth == 8 || P.max_depth == 9)) {
+    if (mode != 2 && !counts_out && pow2 && safev && !resident && !ctx->no_specialise && !ctx->no_bricks && P.max_depth >= 6 && P.max_depth <= 10) {
       const tdt_buffer *cb = ctx->ssbo[TDT_SLOT_CELLS];
       if (ctx->brick_of != cb || ctx->brick_version != cb->version || ctx->brick_depth != P.max_depth) {
-        const size_t need = ((size_t)1 << 15) * tdt::brick_entries(P.max_depth) * sizeof(uint16_t);
+        const bool has_bricks = P.max_depth == 8 || P.max_depth == 9;      // (the other depths: the table alone, levels 6.. walked)
+        const size_t need = has_bricks ? ((size_t)1 << 15) * tdt::brick_entries(P.max_depth) * sizeof(uint16_t) : 0;
         if (!ctx->brick_grid) TDT_HIP(ctx, hipMalloc((void **)&ctx->brick_grid, ((size_t)1 << 15) * sizeof(uint32_t) + sizeof(uint32_t)));
         if (ctx->bricks_bytes < need) {
           if (ctx->bricks) (void)hipFree(ctx->bricks);
@@ -1139,7 +1146,8 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
       if (!ctx->no_bricks && (ctx->brick_of != cb || ctx->brick_version != cb->version || ctx->brick_depth != P.max_depth)) {
         uint32_t *bad = ctx->brick_grid + ((size_t)1 << 15);
         TDT_HIP(ctx, hipMemsetAsync(bad, 0, sizeof(uint32_t), ctx->stream));
-        if (P.max_depth == 9) hipLaunchKernelGGL(tdt::build_bricks_kernel<4>, dim3(1u << 15), dim3(256), 0, ctx->stream, P.cells, P.cells_dwords, ctx->brick_grid, static_cast<uint16_t *>(ctx->bricks), bad);
+        if (P.max_depth != 8 && P.max_depth != 9) hipLaunchKernelGGL(tdt::build_bricks_kernel<0>, dim3(1u << 15), dim3(256), 0, ctx->stream, P.cells, P.cells_dwords, ctx->brick_grid, static_cast<uint16_t *>(nullptr), bad);
+        else if (P.max_depth == 9) hipLaunchKernelGGL(tdt::build_bricks_kernel<4>, dim3(1u << 15), dim3(256), 0, ctx->stream, P.cells, P.cells_dwords, ctx->brick_grid, static_cast<uint16_t *>(ctx->bricks), bad);
         else hipLaunchKernelGGL(tdt::build_bricks_kernel<3>, dim3(1u << 15), dim3(256), 0, ctx->stream, P.cells, P.cells_dwords, ctx->brick_grid, static_cast<uint16_t *>(ctx->bricks), bad);
         TDT_HIP(ctx, hipGetLastError());
         uint32_t flag = 1;
@@ -1157,8 +1165,11 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
       const bool unit = P.scale == 1.0f && P.inv_scale == 1.0f;          // x * 1.0f is x: the UNIT builds do not multiply
 #define TDT_BRICK1(D, U) if (ctx->probe_launch) hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, false, true, true, false, U, true>), grid, block, 0, ctx->stream, P); \
                          else hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, false, true, false, false, U, true>), grid, block, 0, ctx->stream, P)
-      if (brick && P.max_depth == 8) { if (unit) TDT_BRICK1(8, true); else TDT_BRICK1(8, false); launched = true; }
-      if (brick && P.max_depth == 9) { if (unit) TDT_BRICK1(9, true); else TDT_BRICK1(9, false); launched = true; }
+      if (brick) switch (P.max_depth) {
+#define TDT_BRICK2(D) case D: if (unit) TDT_BRICK1(D, true); else TDT_BRICK1(D, false); launched = true; break
+        TDT_BRICK2(6); TDT_BRICK2(7); TDT_BRICK2(8); TDT_BRICK2(9); TDT_BRICK2(10);
+#undef TDT_BRICK2
+        default: break; }
 #undef TDT_BRICK1
 #define TDT_SPEC4(D, R, F, U) if (ctx->probe_launch) hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, R, true, true, F, U>), grid, block, 0, ctx->stream, P); \
                               else hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, R, true, false, F, U>), grid, block, 0, ctx->stream, P)

@@ -493,14 +493,25 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
       return (g & 3u) == 2u;
     }
   } else if constexpr (BRICK && !COUNT) {
-    static_assert(!BRICK || ((DEPTH == 8 || DEPTH == 9) && !RESIDENT && SAFEV), "bricks: depth-8 / depth-9 trees outside the LDS table");
-    constexpr int BL = DEPTH - 5;                     // levels a brick covers: all of them below the table
+    static_assert(!BRICK || (DEPTH >= 6 && DEPTH <= 10 && !RESIDENT && SAFEV), "the 32-bit table: trees of depth 6-10 outside the LDS table");
+    constexpr int BL = (DEPTH == 8 || DEPTH == 9) ? DEPTH - 5 : 0;          // levels a brick covers: all of them below the table (depth 8 / 9), or no bricks
     const float tg = fx0 * 32.0f;                     // exact
     const uint32_t xg = (uint32_t)tg;
-    const uint32_t e = (xg << 10) | ((Yi >> BL) << 5) | (Zi >> BL);
+    const uint32_t e = (xg << 10) | ((Yi >> (DEPTH - 5)) << 5) | (Zi >> (DEPTH - 5));
     const uint32_t g = ns.grid32[e];
     // the band of THIS position: 2^-(11 + k), k from the cell indices its five levels really add the coordinate to (brick_band_exp)
     const float band = __uint_as_float((116u - (g >> 29)) << 23);
+    if constexpr (BL == 0) {                          // the table alone: levels 6.. are walked (PARENT entry: 1 | v << 2 | k << 29)
+      if (__builtin_expect(__ballot(!(__builtin_fabsf(tg - __builtin_rintf(tg)) > band)) == 0ull, 1)) {
+        code = g & 3u;
+        const bool parent = code == 1u;
+        const uint32_t mg = parent ? 5u : (g >> 2) & 15u;
+        v = parent ? (g >> 2) & 0x3FFFFFu : (g >> 6) & 0x7FFFFFu;
+        qx = (1u << mg) | (xg >> (5u - mg));
+        fx = f_fract_nonneg(tg);                      // fract(c * 2^5): level 6's coordinate (only used when code == 1)
+        jumped = true;
+      }
+    } else
     // (two ballots: one of the AND-ed condition goes through a 0 / 1 register and a second compare)
     if (__builtin_expect((__ballot(!(__builtin_fabsf(tg - __builtin_rintf(tg)) > band)) | __ballot((g & 0x7Fu) == 0x7Du)) == 0ull, 1)) {      // 0x7D: PARENT, first exponent 31
       uint32_t ent = g & 0x1FFFFFFFu, xd = xg << BL;  // what the descent ends on (a non-PARENT table entry IS a brick entry below its k); its x digits (the top `levels` count)
