@@ -500,10 +500,11 @@ __device__ __forceinline__ void brick_node(const uint32_t *__restrict__ cells, u
   if (2u * idx + 1u < cells_dwords) { value = cells[2u * idx]; type = cells[2u * idx + 1u]; }     // reads past the end are 0 (robust access)
   code = (type == 0u) ? 0u : (type == 2u ? 2u : 1u);
 }
-template <int BL>                                     // levels a brick covers: 3 (depth 8) or 4 (depth 9); 0: no bricks, the table alone (depths 6, 7, 10)
+template <int BL>                                     // levels a brick covers: depth - 5 for depths 6-9; 0: no bricks, the table alone (depth 10)
 __global__ __launch_bounds__(256) void build_bricks_kernel(const uint32_t *__restrict__ cells, uint32_t cells_dwords, uint32_t *__restrict__ grid32,
                                                            uint16_t *__restrict__ bricks, uint32_t *__restrict__ bad) {
-  constexpr uint32_t kEntries = brick_entries(5 + BL), kStored = BL == 0 ? 1u : (BL == 3 ? 12u + 144u : 12u + 144u + 1728u);   // nodes of the levels kept in LDS
+  constexpr uint32_t kEntries = brick_entries(5 + BL);
+  constexpr uint32_t kStored = BL <= 1 ? 1u : (BL == 2 ? 12u : (BL == 3 ? 12u + 144u : 12u + 144u + 1728u));   // nodes of all brick levels but the last: kept in LDS
   const uint32_t e = blockIdx.x, xg = e >> 10, yg = (e >> 5) & 31u, zg = e & 31u, tid = threadIdx.x;
   uint32_t v = 0, code = 1u, m = 0;
   bool ok = true;
@@ -528,7 +529,8 @@ __global__ __launch_bounds__(256) void build_bricks_kernel(const uint32_t *__res
     if (v >= (1u << 22) && tid == 0) atomicOr(bad, 1u);
     return;
   }
-  // PARENT: v is the level-6 cell.  s_v / s_c: the nodes of level 6 (12: (a + b) x y x z), level 7 (12 below each), level 8 (depth 9)
+  // PARENT: v is the level-6 cell.  s_v / s_c: the nodes of brick level j = 0.. (level 6 + j): 12 ((a + b) x y x z) below each PARENT
+  // of the level above, all levels but the last
   __shared__ uint32_t s_v[kStored], s_c[kStored], s_lo[4], s_hi[4], s_inv;
   if (tid < 4) { s_lo[tid] = 31u; s_hi[tid] = 0u; }
   if (tid == 0) s_inv = 0u;
@@ -538,49 +540,36 @@ __global__ __launch_bounds__(256) void build_bricks_kernel(const uint32_t *__res
     else { const uint32_t ex = 31u - (uint32_t)__builtin_clz(w); atomicMin(&s_lo[level_j], ex); atomicMax(&s_hi[level_j], ex); }
   };
   if (tid == 0) note(0, v);
-  if (tid < 12) {
-    uint32_t w, c;
-    brick_node(cells, cells_dwords, ((2u * v + (tid >> 2)) << 2) + (tid & 3u), w, c);
-    s_v[tid] = w; s_c[tid] = c;
-    if (c == 1u) note(1, w);
-  }
-  __syncthreads();
-  for (uint32_t i = tid; i < 144u; i += 256u) {
-    const uint32_t up = i / 12u, sub = i % 12u;
-    uint32_t w = 0, c = 0;
-    if (s_c[up] == 1u) {
-      brick_node(cells, cells_dwords, ((2u * s_v[up] + (sub >> 2)) << 2) + (sub & 3u), w, c);
-      if (c == 1u) note(2, w);
-    }
-    s_v[12u + i] = w; s_c[12u + i] = c;
-  }
-  __syncthreads();
-  if (BL == 4) {
-    for (uint32_t i = tid; i < 1728u; i += 256u) {
+  uint32_t above = 0u, above_count = 1u, here = 0u;   // where the level above sits in s_v (level -1: the level-5 PARENT itself), where this one goes
+  for (int j = 0; j < BL - 1; j++) {
+    const uint32_t count = above_count * 12u;
+    for (uint32_t i = tid; i < count; i += 256u) {
       const uint32_t up = i / 12u, sub = i % 12u;
+      const uint32_t pv = j == 0 ? v : s_v[above + up], pc = j == 0 ? 1u : s_c[above + up];
       uint32_t w = 0, c = 0;
-      if (s_c[12u + up] == 1u) {
-        brick_node(cells, cells_dwords, ((2u * s_v[12u + up] + (sub >> 2)) << 2) + (sub & 3u), w, c);
-        if (c == 1u) note(3, w);
+      if (pc == 1u) {
+        brick_node(cells, cells_dwords, ((2u * pv + (sub >> 2)) << 2) + (sub & 3u), w, c);
+        if (c == 1u) note(j + 1, w);
       }
-      s_v[156u + i] = w; s_c[156u + i] = c;
+      s_v[here + i] = w; s_c[here + i] = c;
     }
     __syncthreads();
+    above = here; above_count = count; here += count;
   }
   for (uint32_t s = tid; s < kEntries; s += 256u) {
     const uint32_t ci = s >> (2 * BL), yb = (s >> BL) & ((1u << BL) - 1u), zb = s & ((1u << BL) - 1u);
-    uint32_t val = 0, cd = 1u, mm = 5u, at = 0u, base = 0u, count = 12u, div = BL == 3 ? 9u : 27u;
-    uint32_t prev_v = v;
+    uint32_t val = v, cd = 1u, mm = 5u, at = 0u, base = 0u, count = 12u, div = kEntries >> (2 * BL);      // div: 3^BL
     for (int j = 0; j < BL && cd == 1u; j++) {        // level 6 + j
+      div /= 3u;
       const uint32_t c = (ci / div) % 3u, y = (yb >> (BL - 1 - j)) & 1u, z = (zb >> (BL - 1 - j)) & 1u, sub = (c << 2) | (y << 1) | z;
       if (j < BL - 1) {                               // a stored level
         at = at * 12u + sub;
         val = s_v[base + at]; cd = s_c[base + at];
         base += count; count *= 12u;
       } else {
-        brick_node(cells, cells_dwords, ((2u * prev_v + c) << 2) + (y << 1) + z, val, cd);
+        brick_node(cells, cells_dwords, ((2u * val + c) << 2) + (y << 1) + z, val, cd);      // (val: the PARENT above, i.e. this level's cell)
       }
-      prev_v = val; mm = 6u + (uint32_t)j; div /= 3u;
+      mm = 6u + (uint32_t)j;
     }
     if (cd == 2u && val >= 1024u) atomicOr(&s_inv, 1u);
     bricks[(size_t)e * kEntries + s] = (uint16_t)((cd == 2u ? val << 6 : 0u) | (mm << 2) | cd);
@@ -1131,7 +1120,7 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     if (mode != 2 && !counts_out && pow2 && safev && !resident && !ctx->no_specialise && !ctx->no_bricks && P.max_depth >= 6 && P.max_depth <= 10) {
       const tdt_buffer *cb = ctx->ssbo[TDT_SLOT_CELLS];
       if (ctx->brick_of != cb || ctx->brick_version != cb->version || ctx->brick_depth != P.max_depth) {
-        const bool has_bricks = P.max_depth == 8 || P.max_depth == 9;      // (the other depths: the table alone, levels 6.. walked)
+        const bool has_bricks = tdt::brick_levels(P.max_depth) != 0u;     // (depth 10: the table alone, levels 6.. walked)
         const size_t need = has_bricks ? ((size_t)1 << 15) * tdt::brick_entries(P.max_depth) * sizeof(uint16_t) : 0;
         if (!ctx->brick_grid) TDT_HIP(ctx, hipMalloc((void **)&ctx->brick_grid, ((size_t)1 << 15) * sizeof(uint32_t) + sizeof(uint32_t)));
         if (ctx->bricks_bytes < need) {
@@ -1146,9 +1135,12 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
       if (!ctx->no_bricks && (ctx->brick_of != cb || ctx->brick_version != cb->version || ctx->brick_depth != P.max_depth)) {
         uint32_t *bad = ctx->brick_grid + ((size_t)1 << 15);
         TDT_HIP(ctx, hipMemsetAsync(bad, 0, sizeof(uint32_t), ctx->stream));
-        if (P.max_depth != 8 && P.max_depth != 9) hipLaunchKernelGGL(tdt::build_bricks_kernel<0>, dim3(1u << 15), dim3(256), 0, ctx->stream, P.cells, P.cells_dwords, ctx->brick_grid, static_cast<uint16_t *>(nullptr), bad);
-        else if (P.max_depth == 9) hipLaunchKernelGGL(tdt::build_bricks_kernel<4>, dim3(1u << 15), dim3(256), 0, ctx->stream, P.cells, P.cells_dwords, ctx->brick_grid, static_cast<uint16_t *>(ctx->bricks), bad);
-        else hipLaunchKernelGGL(tdt::build_bricks_kernel<3>, dim3(1u << 15), dim3(256), 0, ctx->stream, P.cells, P.cells_dwords, ctx->brick_grid, static_cast<uint16_t *>(ctx->bricks), bad);
+        switch (tdt::brick_levels(P.max_depth)) {
+#define TDT_BUILD_BRICKS(B) case B: hipLaunchKernelGGL(tdt::build_bricks_kernel<B>, dim3(1u << 15), dim3(256), 0, ctx->stream, P.cells, P.cells_dwords, ctx->brick_grid, static_cast<uint16_t *>(ctx->bricks), bad); break
+          TDT_BUILD_BRICKS(1); TDT_BUILD_BRICKS(2); TDT_BUILD_BRICKS(3); TDT_BUILD_BRICKS(4);
+          default: TDT_BUILD_BRICKS(0);
+#undef TDT_BUILD_BRICKS
+        }
         TDT_HIP(ctx, hipGetLastError());
         uint32_t flag = 1;
         TDT_HIP(ctx, hipMemcpyAsync(&flag, bad, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));

@@ -455,7 +455,8 @@ constexpr int kMemoFirst = 3;       // levels 1..3 = cells 0..72 at most: always
 // 8191 at level 5; a sparse tree's top cells have indices in the hundreds, and every wave that walks costs a handful of
 // dependent L2 round trips: 4K/256^3 -20 %).  Checked for every coordinate x level x cell index below the bounds, each with its
 // own band (tdt_selftest 15).
-__host__ __device__ constexpr uint32_t brick_entries(int depth) { return depth == 9 ? 81u * 256u : 27u * 64u; }   // per level-5 position, 2 bytes each; 32768 positions: 113 MB / 1.36 GB of address space, touched where the tree is
+__host__ __device__ constexpr uint32_t brick_levels(int depth) { return depth >= 6 && depth <= 9 ? (uint32_t)(depth - 5) : 0u; }   // levels a brick covers: all below the table (depth 10: none, its levels are walked)
+__host__ __device__ constexpr uint32_t brick_entries(int depth) { uint32_t n = 1u; for (uint32_t j = 0; j < brick_levels(depth); j++) n *= 12u; return n; }   // (3 decisions x 2 y x 2 z) per level   // per level-5 position, 2 bytes each; 32768 positions: 113 MB / 1.36 GB of address space, touched where the tree is
 constexpr uint32_t kBrickLdsCells = 1024u;            // BRICK builds keep a small node table (the walk of waves with a lane in a band starts in it)
 // exponent B of the band (in units of 2^L c, L = 5) a level-l decision with cell index v needs: 2^(5 - l) ulp(v + f), ulp = 2^(floor(log2 v) - 23)
 TDT_DEV int brick_band_exp(int l, uint32_t v) { return (v == 0u ? -40 : (31 - (int)__builtin_clz(v)) + 5 - l - 23); }
@@ -494,7 +495,7 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
     }
   } else if constexpr (BRICK && !COUNT) {
     static_assert(!BRICK || (DEPTH >= 6 && DEPTH <= 10 && !RESIDENT && SAFEV), "the 32-bit table: trees of depth 6-10 outside the LDS table");
-    constexpr int BL = (DEPTH == 8 || DEPTH == 9) ? DEPTH - 5 : 0;          // levels a brick covers: all of them below the table (depth 8 / 9), or no bricks
+    constexpr int BL = (int)brick_levels(DEPTH);      // levels a brick covers: all of them below the table (depths 6-9), or no bricks (depth 10)
     const float tg = fx0 * 32.0f;                     // exact
     const uint32_t xg = (uint32_t)tg;
     const uint32_t e = (xg << 10) | ((Yi >> (DEPTH - 5)) << 5) | (Zi >> (DEPTH - 5));
@@ -525,7 +526,7 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
           ci = ci * 3u + a + b;
           xlow = (xlow << 1) | (a & ~b);
         }
-        constexpr uint32_t kCombos = BL == 3 ? 27u : 81u, kMask = (1u << BL) - 1u;
+        constexpr uint32_t kCombos = BL == 1 ? 3u : (BL == 2 ? 9u : (BL == 3 ? 27u : 81u)), kMask = (1u << BL) - 1u;
         const uint32_t bi = ((__umul24(e, kCombos) + ci) << (2 * BL)) | ((Yi & kMask) << BL) | (Zi & kMask);
         ent = static_cast<const uint16_t *>(ns.bricks)[bi];
         xd |= xlow;
