@@ -32,6 +32,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICR
 
 WORKLOADS = {
     # config id -> (W, H, spp, max_bounce, description, scene config)
+    0: (1280, 720, 4, 6, "the reference's own workload: demo scene (main.rs:235-463, cell_count 100000), 1280x720 window (main.rs:26), 4 spp / max_bounce 6 "
+                         "(assets/settings/camera.ron:2-3)", 0),
     2: (1920, 1080, 64, 8, "1920x1080, 64 spp, max_bounce 8, 64^3 octree terrain+spheres (BASELINE configs[1] scene at the metric's 64 spp)", 2),
     3: (3840, 2160, 64, 16, "3840x2160, 64 spp, max_bounce 16, 256^3 octree (BASELINE configs[2])", 3),
     4: (7680, 4320, 64, 8, "7680x4320, 64 spp, max_bounce 8, 256^3 octree, ONE frame tile-sharded over the ranks (BASELINE configs[3])", 4),
@@ -54,6 +56,10 @@ def parse_args(argv=None):
                          "running sums and hit-record carry through HBM, one resolve at the end (bit-identical to one pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaled 8K block (BASELINE configs[3])")
+    ap.add_argument("--no-target", action="store_true", help="skip the target_4k block (BASELINE configs[2], the north-star roofline config)")
+    ap.add_argument("--no-reference-default", action="store_true", help="skip the reference_default block (demo scene, 1280x720, 4 spp)")
+    ap.add_argument("--target-steps", type=int, default=5)
+    ap.add_argument("--reference-steps", type=int, default=50)
     ap.add_argument("--no-single-process", action="store_true", help="skip the multi-device-context (one process, N GPUs) block")
     ap.add_argument("--strong-steps", type=int, default=3)
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
@@ -133,6 +139,35 @@ def quoted(path, key):
         return None
 
 
+def quoted_valu(wkey):
+    """(SQ-counter summary of the workload's dominant launch, the file it came from): the newest round that has one."""
+    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json"):
+        v = quoted(name, wkey)
+        if v:
+            return v, "profiles/" + name
+    return None, None
+
+
+NOMINAL_BOUND = "algorithmic-bytes/HBM (nominal)"
+NOMINAL_NOTE = ("NOMINAL, not a physical roofline: algorithmic bytes (what a cache-less implementation would fetch: 8 B per tree level visited + the "
+                "material records, SURVEY §8d) over the HBM peak.  The tree is served from LDS / L2 and one table or brick load answers several "
+                "levels, so measured HBM traffic is a small fraction of the algorithmic bytes and this figure may exceed 1; the kernel is "
+                "physically bound by VALU issue x live lanes: see `physical`")
+
+
+def physical_roofline(wkey):
+    """The bound the kernel really runs against: share of the SIMDs' VALU issue slots used x share of the 64 lanes live per issued
+    instruction = fraction of peak useful lane throughput (rocprofv3 SQ counters of the workload's dominant launch, quoted from
+    profiles/: PMC passes cannot run inside a timed bench)."""
+    v, src = quoted_valu(wkey)
+    if not v or v.get("issue_util") is None or v.get("lane_util") is None:
+        return None
+    return {"bound": "valu", "frac": round(v["issue_util"] * v["lane_util"], 4), "issue_util": v["issue_util"], "lane_util": v["lane_util"],
+            "unit": "fraction of peak VALU lane throughput (issue-slot use x live lanes)", "salu_per_valu": round(v["salu_instructions"] / v["valu_wave_instructions"], 4)
+            if v.get("salu_instructions") and v.get("valu_wave_instructions") else None,
+            "kernel_ms_under_pmc": v.get("kernel_ms_under_pmc"), "source": src, "formula": v.get("formula")}
+
+
 def single_process_leg(args):
     """One process, N devices, through tdt_ctx_create_multi: the 8K frame of BASELINE configs[3] (or --config)."""
     import numpy as np
@@ -201,6 +236,17 @@ def run_single_process_child(args, n, timeout_s=240):
     return {"error": f"rc {p.returncode}: " + (p.stderr or p.stdout)[-400:]}
 
 
+def strong_summary(ms_per_frame, trace_ms_per_rank, one_gpu_ms, one_gpu_source, backend, ranks_seen):
+    """The fields that make a strong-scaling line self-explaining: speed-up over one GPU, load imbalance of the per-rank traces,
+    the collective's backend and how many ranks it really saw."""
+    mean = sum(trace_ms_per_rank) / max(1, len(trace_ms_per_rank))
+    return {"speedup_vs_1gpu": round(one_gpu_ms / ms_per_frame, 3) if (one_gpu_ms and ms_per_frame) else None,
+            "one_gpu_ms": round(one_gpu_ms, 3) if one_gpu_ms else None, "one_gpu_source": one_gpu_source,
+            "imbalance": round(max(trace_ms_per_rank) / mean, 4) if mean > 0 else None,
+            "imbalance_note": "max / mean of trace_ms_per_rank (1.0 = perfectly balanced shares)",
+            "backend": backend, "ranks_seen": int(ranks_seen)}
+
+
 def rendezvous_only():
     import torch
     import torch.distributed as dist
@@ -210,10 +256,18 @@ def rendezvous_only():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     t = torch.tensor([float(rank), 1.0], dtype=torch.float64)
     dist.all_reduce(t)
+    # the strong block's summary fields, from numbers every rank contributes over the same process group (self-check of the
+    # N>1 line's arithmetic without a GPU): rank r "traced" for 10 (r + 1) ms, the frame took as long as the slowest
+    tr = torch.zeros(world, dtype=torch.float64)
+    tr[rank] = 10.0 * (rank + 1)
+    dist.all_reduce(tr)
+    seen = dist.get_world_size()
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"rendezvous": world, "rank_sum": t[0].item(), "ranks_seen": int(t[1].item())}), flush=True)
+        trace = [float(v) for v in tr]
+        print(json.dumps({"rendezvous": world, "rank_sum": t[0].item(), "ranks_seen": int(t[1].item()),
+                          "strong": strong_summary(max(trace), trace, sum(trace), "synthetic (sum of the per-rank times)", "gloo", seen)}), flush=True)
 
 
 # ------------------------------------------------------------------------------------------------ a rank ----------
@@ -275,11 +329,13 @@ class Rank:
 class Workload:
     """One scene + camera + image on a rank: a whole image (unsharded) or this rank's tile buffer + gather + assemble."""
 
-    def __init__(self, R, cfg, spp=None, rows_factor=1, passes=1):
+    def __init__(self, R, cfg, spp=None, rows_factor=1, passes=1, alone=False):
+        """alone: this rank traces the whole image by itself, whatever the world size (the 1-GPU reference of the strong block)."""
         import numpy as np  # noqa: F401
         from tdt4230_project_raytracing_amd import host, rt
         torch = R.torch
         self.R, self.rt = R, rt
+        self.sharded = R.sharded and not alone
         W, H, wspp, bounce, desc, scene_cfg = WORKLOADS[cfg]
         self.cfg, self.desc, self.bounce = cfg, desc, bounce
         self.spp = spp or wspp
@@ -294,8 +350,8 @@ class Workload:
         self.dw, self.dh = self.IW + 1, self.IH + 1                      # main.rs:579
         IW, IH, dw, dh = self.IW, self.IH, self.dw, self.dh
         with torch.cuda.stream(R.stream):
-            self.full = torch.zeros((IH, IW, 4), dtype=torch.float32, device=R.dev) if R.rank == 0 else None
-            if not R.sharded:
+            self.full = torch.zeros((IH, IW, 4), dtype=torch.float32, device=R.dev) if (R.rank == 0 or alone) else None
+            if not self.sharded:
                 self.r = rt.Renderer(self.scene, self.cam, device=R.local_rank, stream=R.stream.cuda_stream, image_ptr=self.full.data_ptr())
                 self.tiles_per_rank = 0
                 self.tile_buf = self.gathered = self.full_tex = None
@@ -311,7 +367,7 @@ class Workload:
                 self.full_tex = rt.Texture.wrap_device(self.r.ctx, self.full.data_ptr(), IW, IH, bind=False) if R.rank == 0 else None
             self.carry = torch.zeros((IH, IW, 16), dtype=torch.float32, device=R.dev) if passes > 1 else None
         self.my_pixels = self.r.shader.covered_pixels(dw, dh)
-        if R.sharded:
+        if self.sharded:
             assert self.r.shader.owned_tiles(dw, dh)[0] <= self.tiles_per_rank
         self.trace_events, self.gather_events, self.assemble_events = [], [], []
 
@@ -334,7 +390,7 @@ class Workload:
             e1.record(R.stream)
             if timed:
                 self.trace_events.append((e0, e1))
-            if R.sharded:
+            if self.sharded:
                 e2 = ev()
                 if R.backend == "nccl":
                     glist = list(self.gathered.unbind(0)) if R.rank == 0 else None
@@ -362,6 +418,13 @@ class Workload:
         self.trace_events, self.gather_events, self.assemble_events = [], [], []
         for _ in range(warmup):
             self.step(False, fresh)
+        if not self.sharded:                                 # (an unsharded workload is this rank's own business: no barrier)
+            R.torch.cuda.synchronize(R.dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step(True, fresh)
+            R.torch.cuda.synchronize(R.dev)
+            return (time.perf_counter() - t0) / steps, float(self.my_pixels)
         R.fence()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -378,6 +441,138 @@ class Workload:
 
     def close(self):
         self.r.close()
+
+
+def measure_phases(wl, n=5):
+    """[probe, main, resolve] ms of a history-free frame, from events recorded inside the library on the launch stream."""
+    import numpy as np
+    r = wl.r
+    r.ctx.phase_timing(True)
+    acc = np.zeros(3)
+    for _ in range(n):
+        wl.step(False, True)
+        acc += np.array(r.ctx.phase_timing(True))
+    r.ctx.phase_timing(False)
+    return [float(v) for v in acc / n]
+
+
+def nominal_roofline(R, wl, cfg, phase, frame_kernel_ms):
+    """The `roofline` object for a workload's dominant launch: algorithmic bytes (counted by the instrumented build, untimed) over
+    its duration, against the HBM peak — nominal — with the physical (VALU) bound quoted beside it."""
+    torch = R.torch
+    r, spp, dw, dh, IW, IH = wl.r, wl.spp, wl.dw, wl.dh, wl.IW, wl.IH
+    counts_frame = r.shader.dispatch_counted(dw, dh, 1)        # instrumented, untimed: algorithmic events of the whole frame
+    read_bytes, write_bytes = algorithmic_bytes(counts_frame)
+    kernel_ms, kernel_note, main_read = frame_kernel_ms, "whole dispatch (one launch)", read_bytes
+    if phase is not None and phase[0] > 0:
+        # a two-phase frame: the dominant launch is the main one (samples [spp/16, spp)); count ITS algorithmic events
+        probe = spp // 16
+        with torch.cuda.stream(R.stream):
+            c = torch.zeros((IH, IW, 16), dtype=torch.float32, device=R.dev)
+            wl.full.zero_()
+        R.stream.synchronize()
+        r.shader.dispatch_counted_range(dw, dh, 1, 0, probe, c.data_ptr())      # (instrumented too: keeps the product kernel's profile rows to whole launches)
+        counts_main = r.shader.dispatch_counted_range(dw, dh, 1, probe, spp - probe, c.data_ptr())
+        main_read, _ = algorithmic_bytes(counts_main)
+        kernel_ms, kernel_note = phase[1], f"main launch of the two-phase frame: samples [{probe}, {spp}) of every pixel in the cost order of this frame's probe"
+        del c
+    achieved = main_read / (kernel_ms * 1e-3) / 1e9
+    wkey = f"config{cfg}_spp{spp}_gpus{R.world}"
+    traffic = (quoted("traffic.json", wkey) or {}).get("hbm_bytes_per_launch")
+    valu, _ = quoted_valu(wkey)
+    return {"bound": NOMINAL_BOUND, "bound_note": NOMINAL_NOTE,
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": traffic, "traffic_note": "measured HBM bytes of the same launch (rocprofv3 TCC counters, profiles/traffic.json): << algorithmic",
+            "physical": physical_roofline(wkey),
+            "kernel": "tdt::trace_kernel<false, ...> (COUNT = false: the product build)", "kernel_launch": kernel_note,
+            "kernel_ms": round(kernel_ms, 4), "algorithmic_read_bytes": int(main_read),
+            "frame": {"dispatch_ms": round(frame_kernel_ms, 4), "algorithmic_read_bytes": int(read_bytes), "algorithmic_write_bytes": int(write_bytes),
+                      "node_loads": counts_frame["node_loads"], "rays": counts_frame["octree_hit_calls"],
+                      "frac_of_hbm_peak": round(read_bytes / (frame_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "phases_ms": {"probe": round(phase[0], 4), "main": round(phase[1], 4), "resolve": round(phase[2], 4)} if phase else None,
+            "valu": valu}
+
+
+def oracle_bands(wl, bands, band_rows, cores):
+    """Rows [y0, y0 + band_rows) of `bands` bands of the workload's frame on the CPU oracle (the checker; a port, not the
+    product): (seconds, pixels, mismatching pixels of the GPU frame in those rows)."""
+    import numpy as np
+    R, r = wl.R, wl.r
+    r.ctx.forget_costs()
+    r.shader.dispatch_compute(wl.dw, wl.dh, 1)
+    R.stream.synchronize()
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    orc = oracle_py.Oracle()
+    IW, IH = wl.IW, wl.IH
+    covered_h = min(max(wl.dh // 32, 1) * 32, IH)
+    ys = [int(i * (covered_h - band_rows) / max(1, bands - 1)) // 8 * 8 for i in range(bands)]
+    img = np.zeros((IH, IW, 4), np.float32)
+    t0 = time.perf_counter()
+    px = 0
+    for y0 in ys:
+        orc.render(wl.scene, wl.cam, (wl.dw, wl.dh), rows=(y0, y0 + band_rows), threads=cores, image=img)
+        px += IW * band_rows
+    tc = time.perf_counter() - t0
+    got = wl.full.cpu().numpy()
+    bad = 0
+    for y0 in ys:
+        bad += int((got[y0:y0 + band_rows].view(np.uint32) != img[y0:y0 + band_rows].view(np.uint32)).any(axis=2).sum())
+    return tc, px, bad
+
+
+def target_block(R, args):
+    """BASELINE configs[2] — 3840x2160 / 64 spp / max_bounce 16 / 256^3: the configuration north_star quotes its roofline target on."""
+    wl = Workload(R, 3)
+    sec, px = wl.run(args.target_steps, 2, True)
+    frame_ms = Workload.mean_ms(wl.trace_events)
+    phase = measure_phases(wl, 3)
+    wl.step(False, False)
+    rsec, _ = wl.run(args.target_steps, 1, False)
+    roof = nominal_roofline(R, wl, 3, phase, frame_ms)
+    out = {"workload": WORKLOADS[3][4], "image": [wl.IW, wl.IH], "dispatch": [wl.dw, wl.dh, 1], "spp": wl.spp, "max_bounce": wl.bounce,
+           "written_pixels": int(px), "octree_max_depth": wl.scene.max_depth, "octree_cells": wl.scene.counts["cells"],
+           "steps": args.target_steps, "history_free_ms": round(sec * 1e3, 3), "replay_ms": round(rsec * 1e3, 3),
+           "value": round(px * wl.spp / sec / 1e6, 2), "unit": "Mray-samples/s",
+           "schedule": "every timed step history-free (tdt_forget_costs before it), as the headline; replay_ms = the identical frame again",
+           "roofline": roof, "target": "north_star: >= 40 % of the HBM-read roofline (nominal definition) on this configuration"}
+    wl.close()
+    return out
+
+
+def reference_default_block(R, args):
+    """What the reference's own main.rs renders every frame: its demo scene at its window size and camera.ron settings.
+    cell_count = 100000 is not a power of two: the per-cell threshold builds (FORM_TABLE) trace it; the literal-formula kernel
+    (TDT_NO_TABLE_FORM=1: what every such scene ran before round 3) is timed beside it on the same frame."""
+    steps = args.reference_steps
+    wl = Workload(R, 0)
+    sec, px = wl.run(steps, 5, True)
+    wl.step(False, False)
+    rsec, _ = wl.run(steps, 1, False)
+    cores = min(os.cpu_count() or 1, 32)
+    tc, opx, bad = oracle_bands(wl, 8, 8, cores)
+    spp = wl.spp
+    out = {"workload": WORKLOADS[0][4], "image": [wl.IW, wl.IH], "dispatch": [wl.dw, wl.dh, 1], "spp": spp, "max_bounce": wl.bounce,
+           "written_pixels": int(px), "octree_max_depth": wl.scene.max_depth, "cell_count": wl.scene.cell_count, "steps": steps,
+           "history_free_ms": round(sec * 1e3, 4), "replay_ms": round(rsec * 1e3, 4), "value": round(px * spp / sec / 1e6, 2), "unit": "Mray-samples/s",
+           "schedule": "spp < 16: a frame the scheduler has not seen is ONE launch in image order (no probe); replay_ms = the identical frame again in its recorded cost order",
+           "oracle_check": {"bands": 8, "rows_per_band": 8, "pixels": opx, "mismatched_pixels": bad, "oracle_s": round(tc, 2), "cores": cores,
+                            "oracle_value": round(opx * spp / tc / 1e6, 3)},
+           "reference_llvmpipe": quoted("llvmpipe_baseline.json", f"config0_spp{spp}")}
+    wl.close()
+    os.environ["TDT_NO_TABLE_FORM"] = "1"                    # read when a context is created
+    try:
+        gl = Workload(R, 0)
+        gsec, _ = gl.run(steps, 5, True)
+        gl.step(False, False)
+        grsec, _ = gl.run(steps, 1, False)
+        gl.close()
+    finally:
+        del os.environ["TDT_NO_TABLE_FORM"]
+    out["literal_kernel"] = {"history_free_ms": round(gsec * 1e3, 4), "replay_ms": round(grsec * 1e3, 4), "value": round(px * spp / gsec / 1e6, 2),
+                             "note": "trace_kernel<false, FORM_LITERAL>: float treeLookup, no tables (TDT_NO_TABLE_FORM=1)"}
+    out["speedup_vs_literal_kernel"] = round(gsec / sec, 3)
+    return out
 
 
 def main():
@@ -434,15 +629,7 @@ def main():
     rank_trace_ms = R.gather_floats(frame_kernel_ms)
 
     # phases of a history-free frame (probe / main / resolve) from events recorded inside the library, a few more frames
-    phase = None
-    if fresh and rank == 0 and not R.sharded:
-        r.ctx.phase_timing(True)
-        acc = np.zeros(3)
-        for _ in range(5):
-            wl.step(False, True)
-            acc += np.array(r.ctx.phase_timing(True))
-        phase = [float(v) for v in acc / 5]
-        r.ctx.phase_timing(False)
+    phase = measure_phases(wl, 5) if (fresh and rank == 0 and not R.sharded) else None
 
     # ---- the other schedule, for the record -----------------------------------------------------------------------------
     other_ms = None
@@ -452,69 +639,28 @@ def main():
         other_ms = other_sec * 1e3
 
     # ---- roofline of the dominant kernel: the main launch of the frame, measured on rank 0 ------------------------------
-    roofline = None
-    if rank == 0:
-        counts_frame = r.shader.dispatch_counted(dw, dh, 1)        # instrumented, untimed: algorithmic events of the whole frame
-        read_bytes, write_bytes = algorithmic_bytes(counts_frame)
-        kernel_ms, kernel_note, main_read = frame_kernel_ms, "whole dispatch (one launch)", read_bytes
-        if phase is not None and phase[0] > 0:
-            # a two-phase frame: the dominant launch is the main one (samples [spp/16, spp)); count ITS algorithmic events
-            probe = spp // 16
-            with torch.cuda.stream(R.stream):
-                c = torch.zeros((IH, IW, 16), dtype=torch.float32, device=R.dev)
-                wl.full.zero_()
-            R.stream.synchronize()
-            r.shader.dispatch_counted_range(dw, dh, 1, 0, probe, c.data_ptr())      # (instrumented too: keeps the product kernel's profile rows to whole launches)
-            counts_main = r.shader.dispatch_counted_range(dw, dh, 1, probe, spp - probe, c.data_ptr())
-            main_read, _ = algorithmic_bytes(counts_main)
-            kernel_ms, kernel_note = phase[1], f"main launch of the two-phase frame: samples [{probe}, {spp}) of every pixel in the cost order of this frame's probe"
-            del c
-        achieved = main_read / (kernel_ms * 1e-3) / 1e9
-        wkey = f"config{args.config}_spp{spp}_gpus{world}"
-        traffic = (quoted("traffic.json", wkey) or {}).get("hbm_bytes_per_launch")
-        valu = quoted("r02_pmc_summary.json", wkey)
-        roofline = {"bound": "hbm", "bound_note": "NOMINAL: algorithmic bytes (what a cache-less implementation would fetch: 8 B per tree level visited, SURVEY §8d) "
-                             "over the HBM peak.  The tree is served from LDS / L2, so measured HBM traffic is far below the algorithmic bytes and the "
-                             "kernel is physically bound by VALU issue and lane divergence: see `valu`",
-                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": traffic, "traffic_note": "measured HBM bytes per frame (rocprofv3 TCC counters, profiles/traffic.json): << algorithmic",
-                    "kernel": "tdt::trace_kernel<false, ...> (COUNT = false: the product build)", "kernel_launch": kernel_note,
-                    "kernel_ms": round(kernel_ms, 4), "algorithmic_read_bytes": int(main_read),
-                    "frame": {"dispatch_ms": round(frame_kernel_ms, 4), "algorithmic_read_bytes": int(read_bytes), "algorithmic_write_bytes": int(write_bytes),
-                              "node_loads": counts_frame["node_loads"], "rays": counts_frame["octree_hit_calls"],
-                              "frac_of_hbm_peak": round(read_bytes / (frame_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
-                    "phases_ms": {"probe": round(phase[0], 4), "main": round(phase[1], 4), "resolve": round(phase[2], 4)} if phase else None,
-                    "valu": valu}
+    roofline = nominal_roofline(R, wl, args.config, phase, frame_kernel_ms) if rank == 0 else None
 
     # ---- CPU baseline: the oracle (a port, not the product) on a bounded sample; the reference's own llvmpipe figure quoted ----
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        r.ctx.forget_costs()
-        r.shader.dispatch_compute(dw, dh, 1)
-        R.stream.synchronize()
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle_py
-        orc = oracle_py.Oracle()
         cores = min(os.cpu_count() or 1, 32)
         bands, band_rows = 96, 8
-        ys = [int(i * (IH - 32) / bands) // 8 * 8 for i in range(bands)]
-        img = np.zeros((IH, IW, 4), np.float32)
-        t0 = time.perf_counter()
-        px = 0
-        for y0 in ys:
-            orc.render(scene, cam, (dw, dh), rows=(y0, y0 + band_rows), threads=cores, image=img)
-            px += IW * band_rows
-        tc = time.perf_counter() - t0
+        tc, px, bad = oracle_bands(wl, bands, band_rows, cores)
         cpu_baseline = {"value": round(px * spp / tc / 1e6, 3), "unit": "Mray-samples/s", "cores": cores, "kind": "port",
-                        "sample": f"{bands} bands of {band_rows} rows ({px} px x {spp} spp) of the same frame, {tc:.1f} s"}
-        # spot-check the product against the checker on the sampled rows (never the other way round)
-        got = wl.full.cpu().numpy()
-        bad = 0
-        for y0 in ys:
-            bad += int((got[y0:y0 + band_rows].view(np.uint32) != img[y0:y0 + band_rows].view(np.uint32)).any(axis=2).sum())
-        cpu_baseline["mismatched_pixels_in_sample"] = bad
-        cpu_baseline["reference_llvmpipe"] = quoted("llvmpipe_baseline.json", f"config{args.config}_spp{spp}")
+                        "sample": f"{bands} bands of {band_rows} rows ({px} px x {spp} spp) of the same frame, {tc:.1f} s",
+                        # the product spot-checked against the checker on the sampled rows (never the other way round)
+                        "mismatched_pixels_in_sample": bad,
+                        "reference_llvmpipe": quoted("llvmpipe_baseline.json", f"config{args.config}_spp{spp}")}
     wl.close()
+
+    # ---- BASELINE configs[2] (the north-star roofline configuration) and the reference's own workload: N = 1 lines only ------
+    target_4k = reference_default = None
+    if world == 1 and not R.sharded and not progressive and args.config == 2:
+        if not args.no_target:
+            target_4k = target_block(R, args)
+        if not args.no_reference_default:
+            reference_default = reference_default_block(R, args)
 
     # ---- BASELINE configs[3]: ONE 8K frame, strong-sharded over the ranks -------------------------------------------------
     strong = None
@@ -531,6 +677,15 @@ def main():
                   "tile_buffer_bytes_per_rank": int(sw.tiles_per_rank) * 32 * 32 * 16,
                   "schedule": "every frame history-free (tdt_forget_costs): two-phase on each rank"}
         sw.close()
+        # the same frame on ONE GPU, in this run: rank 0 alone (the others wait at the fence below); at N = 1 it is the measurement above
+        one_ms, one_src = ssec * 1e3, "this measurement (one rank)"
+        if world > 1 and rank == 0:
+            ow = Workload(R, 4, alone=True)
+            osec, _ = ow.run(1, 1, True)
+            ow.close()
+            one_ms, one_src = osec * 1e3, "rank 0 alone, same run: 1 warm-up + 1 timed history-free frame"
+        strong.update(strong_summary(ssec * 1e3, strace, one_ms, one_src, R.backend if R.sharded else "none (one rank: no collective)",
+                                     R.dist.get_world_size() if R.sharded else 1))
 
     R.fence()
     R.close()
@@ -569,6 +724,8 @@ def main():
                    "partition": f"32x32 work-groups dealt round-robin over {world} rank(s)" + ("; one RCCL gather + de-interleave per step" if R.sharded else "")},
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
+        "target_4k": target_4k,
+        "reference_default": reference_default,
         "strong": strong,
         "single_process": single,
     }

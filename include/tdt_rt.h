@@ -80,8 +80,12 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out);
  * devices) and de-interleaves them there into the bound image, so tdt_image_read / tdt_image_read_rgba8 /
  * tdt_image_device_ptr see the assembled frame on device_ids[0].  Device ids may repeat (several shares on one GPU — how
  * the path is tested on a one-GPU box); RCCL cannot form a communicator then and the gather becomes peer copies ordered
- * by events (TDT_MULTI_TRANSPORT=copy forces that, =rccl forbids it).  Not available on a multi-device context (they
- * return TDT_ERR_INVALID_OPERATION): tdt_set_partition, tdt_dispatch_accumulate / _resolve / _counted_range. */
+ * by events (TDT_MULTI_TRANSPORT=copy forces that, =rccl forbids it).  Progressive passes work on a node too:
+ * tdt_dispatch_accumulate keeps every device's running sums (and, when carry_device_ptr is non-NULL, its hit-record carry, in
+ * memory the context allocates per device — the pointer itself is not used) in that device's tile buffer, and
+ * tdt_dispatch_resolve resolves per device, then gathers and assembles.  A dispatch that fails on one device drains the
+ * devices already launched and leaves the context ready for the next frame.  Not available on a multi-device context
+ * (TDT_ERR_INVALID_OPERATION): tdt_set_partition, tdt_dispatch_counted_range. */
 int tdt_ctx_create_multi(int n_devices, const int *device_ids, tdt_ctx **out);
 /* number of devices behind a context (1 for tdt_ctx_create) */
 int tdt_ctx_device_count(const tdt_ctx *ctx);
@@ -198,6 +202,11 @@ int tdt_debug_phase_timing(tdt_ctx *ctx, int enable, float ms[3]);
 int tdt_debug_multi_timing(tdt_ctx *ctx, float *trace_ms /* n_devices */, float *gather_ms, float *assemble_ms);
 /* which transport the last gather of a multi-device context used: "rccl", "copy", or "" */
 const char *tdt_debug_multi_transport(const tdt_ctx *ctx);
+/* ranks of the RCCL communicator the context really created (0: none — single-device context, or the copy transport) */
+int tdt_debug_multi_rccl_ranks(const tdt_ctx *ctx);
+/* test hook: the next raytracer dispatch of a multi-device context fails at device index `member` after the devices before
+ * it were launched (-1: cancel) — exercises the drain-and-reset path of a half-launched frame */
+int tdt_debug_multi_fail(tdt_ctx *ctx, int member);
 
 /* ---- scene ingest on the GPU ------------------------------------------------------------------------
  * The step the reference never wrote (its call is commented out, main.rs:218-224): turn the voxel list its PLY loader
@@ -256,6 +265,14 @@ int tdt_debug_pixel_log(tdt_ctx *ctx, uint32_t *out, size_t n_u32);
  * harness: the raw reciprocal seed, the claims without the bands, the short normal without its guard, the divisions without
  * the residual step, the wrong binade, and half the band, must fail. */
 int tdt_selftest(tdt_ctx *ctx, int which, uint64_t *mismatches);
+/* A cell_count that is not a power of two (the reference's own: 100000, main.rs:459) takes treeLookup's x index
+ * (raytracer.comp:376-378) through two per-cell thresholds on the level's coordinate instead of the float formula (csrc/
+ * trace_device.hpp, x_thresholds).  This checks that claim exhaustively for one (cell_count, inv_cell_count) pair: every
+ * coordinate f in [0,1) x every cell index below n_cells (<= 65535) against the literal formula; *mismatches must be 0.
+ * *shape_ok = 0: some cell's index is not a two-step function of f — such a scene runs the literal kernel.  shift != 0 moves
+ * every threshold by that many ulps first (the harness: mismatches must appear). */
+int tdt_selftest_index(tdt_ctx *ctx, int32_t cell_count, float inv_cell_count, uint32_t n_cells, int shift, uint64_t *mismatches,
+                       int *shape_ok);
 
 #ifdef __cplusplus
 }

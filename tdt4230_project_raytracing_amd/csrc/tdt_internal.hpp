@@ -63,7 +63,8 @@ struct tdt_ctx {
   CostSig cost_sig;                    // what those costs were measured on (camera, octree parameters, buffer versions, partition)
   bool no_cost_order;           // TDT_NO_COST_ORDER=1: always hand work-groups out in image order
   uint32_t *scan;               // device scratch of scan_cells_kernel
-  uint32_t max_parent_value, max_any_value;   // its result for `packed_of`
+  uint32_t max_parent_value, max_any_value, live_nodes;   // its result for `packed_of` (live_nodes: one past the last node that is not all zeros)
+  float *thr; int32_t thr_cc; uint32_t thr_ic_bits, thr_n; float thr_f0max; bool thr_ok, no_table_form;   // FORM_TABLE builds: per-cell x-index thresholds for (cell_count, inv_cell_count) over thr_n cells (TDT_NO_TABLE_FORM=1: off)
   int num_cus;
   bool force_generic;   // TDT_FORCE_GENERIC=1: always run the literal-arithmetic kernel (A/B testing)
   int event_threshold;  // TDT_EVENT_THRESHOLD=n fixes the event threshold (experiments); 0 = adaptive
@@ -131,6 +132,8 @@ int multi_buffer_sub_data(tdt_buffer *b, size_t offset, size_t bytes, const void
 int multi_image_create(tdt_ctx *ctx, void *device_ptr, int width, int height, tdt_image **out);
 void multi_image_destroy(tdt_image *img);
 int multi_dispatch_compute(tdt_compute *c, int width, int height, int depth);
+int multi_dispatch_accumulate(tdt_compute *c, int width, int height, int depth, int spp_begin, int spp_count, void *carry);
+int multi_dispatch_resolve(tdt_compute *c, int width, int height, int depth, int total_spp);
 int multi_dispatch_counted(tdt_compute *c, int width, int height, int depth, uint64_t counts[8]);
 int multi_forget_costs(tdt_ctx *ctx);
 tdt_ctx *multi_first_member(tdt_ctx *front);

@@ -54,6 +54,9 @@ struct Multi {
   const char *last_transport = "";
   Rccl rccl;
   std::vector<void *> comm;
+  int fail_member = -1;                                    // tdt_debug_multi_fail: the next raytracer dispatch fails at this member (tests)
+  std::vector<void *> carry; size_t carry_bytes = 0;       // progressive passes: per member, the hit-record carry of its tile buffer
+  int acc_tiles = 0;                                       // tiles per member of the running sums the tile buffers hold (0: none)
 };
 
 static int member_fail(tdt_ctx *front, tdt_ctx *m, int rc) {
@@ -115,6 +118,8 @@ void multi_destroy(tdt_ctx *front) {
     (void)hipSetDevice(M->member[0]->device);
     if (front->counters) (void)hipFree(front->counters);      // tdt_selftest on the front
     if (M->gathered) (void)hipFree(M->gathered);
+    for (size_t i = 0; i < M->carry.size(); i++) if (M->carry[i]) { (void)hipSetDevice(M->member[i]->device); (void)hipFree(M->carry[i]); }
+    (void)hipSetDevice(M->member[0]->device);
     if (M->ev_gathered) (void)hipEventDestroy(M->ev_gathered);
     if (M->ev_assembled) (void)hipEventDestroy(M->ev_assembled);
   }
@@ -264,37 +269,22 @@ static int ensure_frame_buffers(tdt_ctx *front, int tiles_per_member) {
   return TDT_OK;
 }
 
-int multi_dispatch_compute(tdt_compute *c, int width, int height, int depth) {
-  tdt_ctx *front = c->ctx;
+// A frame that fails half-way must not leave the front in a state the next frame trips over: members that were launched are
+// drained (their streams may still be writing tile buffers a retry would rebind) and the "a frame has been dispatched" flag —
+// which the next frame's hipStreamWaitEvent(ev_gathered) and tdt_debug_multi_timing rely on — is reset.
+static void abandon_frame(tdt_ctx *front, int launched) {
+  Multi &M = *front->multi;
+  for (int j = 0; j < launched && j < (int)M.member.size(); j++) {
+    (void)hipSetDevice(M.member[j]->device);
+    (void)hipStreamSynchronize(M.member[j]->stream);
+  }
+  M.timed = false; M.acc_tiles = 0;
+}
+
+// the ONE gather of per-device tile buffers to the first device, then the de-interleave into the front's image
+static int gather_and_assemble(tdt_ctx *front, tdt_compute *c, tdt_image *img, int width, int height, int depth) {
   Multi &M = *front->multi;
   const int n = (int)M.member.size();
-  if (c->kind == TDT_PROGRAM_OCTREE_UPDATE) {          // an edit changes every replica of the scene, identically
-    for (int i = 0; i < n; i++) TDT_MEMBER(front, M.member[i], tdt_dispatch_compute(c->replicas[i], width, height, depth));
-    return TDT_OK;
-  }
-  if (!front->image0) return fail(front, TDT_ERR_INCOMPLETE, "no image bound to unit 0");
-  tdt_image *img = front->image0;
-  if (img->w != c->image_width || img->h != c->image_height)
-    return fail(front, TDT_ERR_INVALID_OPERATION, "bound image is not camera.image_width x image_height");
-  const Cover k = cover_of(c, width, height);
-  const Tiles t = tiles_of(c, k);                        // the front's partition is (0, 1): totals
-  if (t.total <= 0) return TDT_OK;
-  const int tpm = (t.total + n - 1) / n;                 // what member 0 owns: the most
-  int rc = ensure_frame_buffers(front, tpm);
-  if (rc == TDT_OK) rc = choose_transport(front);
-  if (rc != TDT_OK) return rc;
-  for (int i = 0; i < n; i++) {
-    tdt_ctx *m = M.member[i];
-    TDT_HIP(front, hipSetDevice(m->device));
-    // copy transport: member 0's stream reads this member's tile buffer; the next frame must not overwrite it earlier
-    // (with RCCL the gather runs on the member's own stream, which orders it)
-    if (M.transport == 2 && M.timed && i > 0) TDT_HIP(front, hipStreamWaitEvent(m->stream, M.ev_gathered, 0));
-    TDT_HIP(front, hipEventRecord(M.ev_begin[i], m->stream));
-    TDT_MEMBER(front, m, tdt_bind_image(m, 0, M.tile[i]));
-    TDT_MEMBER(front, m, tdt_dispatch_compute(c->replicas[i], width, height, depth));
-    TDT_HIP(front, hipEventRecord(M.ev_traced[i], m->stream));
-  }
-  // ---- the ONE gather of per-device tile buffers to the first device
   tdt_ctx *m0 = M.member[0];
   const size_t count = (size_t)M.tiles_per_member * 1024 * 4;        // floats per member
   if (M.transport == 1) {
@@ -318,8 +308,86 @@ int multi_dispatch_compute(tdt_compute *c, int width, int height, int depth) {
   TDT_HIP(front, hipEventRecord(M.ev_gathered, m0->stream));
   TDT_MEMBER(front, m0, tdt_assemble_tiles(c->replicas[0], M.gathered, n, M.tiles_per_member, img->full, width, height, depth));
   TDT_HIP(front, hipEventRecord(M.ev_assembled, m0->stream));
-  M.timed = true;
   return TDT_OK;
+}
+
+// what: 0 = tdt_dispatch_compute (a whole frame), 1 = tdt_dispatch_accumulate (samples [spp_begin, spp_begin + spp_count) added to
+// the running sums in the members' tile buffers; no gather), 2 = tdt_dispatch_resolve (resolve on every member, then gather + assemble)
+static int member_launch(tdt_ctx *front, tdt_compute *c, int i, int what, int width, int height, int depth, int spp_begin, int spp_count, bool use_carry, int total_spp) {
+  Multi &M = *front->multi;
+  tdt_ctx *m = M.member[i];
+  TDT_HIP(front, hipSetDevice(m->device));
+  // copy transport: member 0's stream reads this member's tile buffer; the next frame must not overwrite it earlier
+  // (with RCCL the gather runs on the member's own stream, which orders it)
+  if (M.transport == 2 && M.timed && i > 0 && what != 2) TDT_HIP(front, hipStreamWaitEvent(m->stream, M.ev_gathered, 0));
+  if (what != 2) TDT_HIP(front, hipEventRecord(M.ev_begin[i], m->stream));
+  TDT_MEMBER(front, m, tdt_bind_image(m, 0, M.tile[i]));
+  if (M.fail_member == i) { M.fail_member = -1; return fail(front, TDT_ERR_INVALID_OPERATION, "device " + std::to_string(m->device) + ": failure injected by tdt_debug_multi_fail"); }
+  if (what == 0) TDT_MEMBER(front, m, tdt_dispatch_compute(c->replicas[i], width, height, depth));
+  else if (what == 1) TDT_MEMBER(front, m, tdt_dispatch_accumulate(c->replicas[i], width, height, depth, spp_begin, spp_count, use_carry ? M.carry[i] : nullptr));
+  else TDT_MEMBER(front, m, tdt_dispatch_resolve(c->replicas[i], width, height, depth, total_spp));
+  TDT_HIP(front, hipEventRecord(M.ev_traced[i], m->stream));
+  return TDT_OK;
+}
+
+static int multi_frame(tdt_compute *c, int what, int width, int height, int depth, int spp_begin, int spp_count, bool use_carry, int total_spp) {
+  tdt_ctx *front = c->ctx;
+  Multi &M = *front->multi;
+  const int n = (int)M.member.size();
+  if (!front->image0) return fail(front, TDT_ERR_INCOMPLETE, "no image bound to unit 0");
+  tdt_image *img = front->image0;
+  if (img->w != c->image_width || img->h != c->image_height)
+    return fail(front, TDT_ERR_INVALID_OPERATION, "bound image is not camera.image_width x image_height");
+  const Cover k = cover_of(c, width, height);
+  const Tiles t = tiles_of(c, k);                        // the front's partition is (0, 1): totals
+  if (t.total <= 0) return TDT_OK;
+  const int tpm = (t.total + n - 1) / n;                 // what member 0 owns: the most
+  if (what == 2 && M.acc_tiles != tpm) return fail(front, TDT_ERR_INVALID_OPERATION, "resolve without accumulated passes of the same dispatch size on this context");
+  if (what == 1 && spp_begin != 0 && M.acc_tiles != tpm)
+    return fail(front, TDT_ERR_INVALID_OPERATION, "a pass that continues running sums (spp_begin > 0) needs earlier passes of the same dispatch size on this context");
+  int rc = ensure_frame_buffers(front, tpm);             // (a larger frame re-allocates the tile buffers: running sums start over, checked above)
+  if (rc == TDT_OK) rc = choose_transport(front);
+  if (rc == TDT_OK && what == 1 && use_carry) {
+    const size_t need = (size_t)M.tiles_per_member * 1024 * 16 * sizeof(float);
+    if (M.carry.size() != (size_t)n || M.carry_bytes < need) {
+      for (size_t i = 0; i < M.carry.size(); i++) if (M.carry[i]) { (void)hipSetDevice(M.member[i]->device); (void)hipFree(M.carry[i]); }
+      M.carry.assign(n, nullptr); M.carry_bytes = 0;
+      for (int i = 0; i < n && rc == TDT_OK; i++) {
+        if (hipSetDevice(M.member[i]->device) != hipSuccess || hipMalloc(&M.carry[i], need) != hipSuccess) rc = fail(front, TDT_ERR_HIP, "carry allocation on device " + std::to_string(M.member[i]->device));
+      }
+      if (rc == TDT_OK) M.carry_bytes = need;
+    }
+  }
+  if (rc != TDT_OK) return rc;
+  for (int i = 0; i < n; i++) {
+    rc = member_launch(front, c, i, what, width, height, depth, spp_begin, spp_count, use_carry, total_spp);
+    if (rc != TDT_OK) { abandon_frame(front, i); return rc; }
+  }
+  if (what == 1) { M.acc_tiles = tpm; return TDT_OK; }   // running sums stay in the tile buffers until the resolve
+  rc = gather_and_assemble(front, c, img, width, height, depth);
+  if (rc != TDT_OK) { abandon_frame(front, n); return rc; }
+  M.timed = true; M.acc_tiles = 0;
+  return TDT_OK;
+}
+
+int multi_dispatch_compute(tdt_compute *c, int width, int height, int depth) {
+  tdt_ctx *front = c->ctx;
+  Multi &M = *front->multi;
+  if (c->kind == TDT_PROGRAM_OCTREE_UPDATE) {          // an edit changes every replica of the scene, identically
+    for (size_t i = 0; i < M.member.size(); i++) TDT_MEMBER(front, M.member[i], tdt_dispatch_compute(c->replicas[i], width, height, depth));
+    return TDT_OK;
+  }
+  return multi_frame(c, 0, width, height, depth, 0, 0, false, 0);
+}
+
+// Progressive passes on a node (BASELINE configs[4]'s 1024 spp as passes): every member keeps the running sums of ITS work-groups in
+// its tile buffer and the hit-record carry beside it (allocated here: `carry` device memory of a single-device host would be on
+// one GPU only — a non-null pointer just says "carry the records"); the resolve runs per member, then the one gather + assemble.
+int multi_dispatch_accumulate(tdt_compute *c, int width, int height, int depth, int spp_begin, int spp_count, void *carry) {
+  return multi_frame(c, 1, width, height, depth, spp_begin, spp_count, carry != nullptr, 0);
+}
+int multi_dispatch_resolve(tdt_compute *c, int width, int height, int depth, int total_spp) {
+  return multi_frame(c, 2, width, height, depth, 0, 0, false, total_spp);
 }
 
 int multi_dispatch_counted(tdt_compute *c, int width, int height, int depth, uint64_t counts[8]) {
@@ -401,6 +469,19 @@ int tdt_debug_multi_timing(tdt_ctx *ctx, float *trace_ms, float *gather_ms, floa
   TDT_HIP(ctx, hipEventElapsedTime(&a, M.ev_gathered, M.ev_assembled));
   if (gather_ms) *gather_ms = g;
   if (assemble_ms) *assemble_ms = a;
+  return TDT_OK;
+}
+
+int tdt_debug_multi_rccl_ranks(const tdt_ctx *ctx) {
+  if (!ctx || !ctx->multi || ctx->multi->transport != 1) return 0;
+  int n = 0;
+  for (void *c : ctx->multi->comm) n += c ? 1 : 0;
+  return n;
+}
+
+int tdt_debug_multi_fail(tdt_ctx *ctx, int member) {
+  if (!ctx || !ctx->multi || member < -1 || member >= (int)ctx->multi->member.size()) return TDT_ERR_INVALID_VALUE;
+  ctx->multi->fail_member = member;
   return TDT_OK;
 }
 

@@ -71,11 +71,12 @@ enum : int { ST_DONE = -1, ST_TRAVERSE = 0, ST_HIT = 1, ST_END = 2, ST_FETCH = 3
 // P.accumulate == 0: the whole of main() rc:234-252; 1: only the sample loop, adding to running sums (a uniform run-time
 // flag, looked at once per pixel, so the scene-specialised variants serve progressive passes too).
 // COUNT: instrumented build that also totals the events defining the algorithmic bytes.
-// POW2: exact-comparison treeLookup (see tree_lookup_pow2) vs the literal float form.
-// PROBE changes nothing but the kernel's name: the short probe launch of a two-phase frame (tdt_dispatch_compute) then shows
-// up as its own row in profiler statistics instead of halving the average of the launches that do the work.
-template <bool COUNT, bool POW2, int DEPTH = 0, bool RESIDENT = false, bool SAFEV = false, bool PROBE = false, bool FULL = false, bool UNIT = false, bool BRICK = false>
+// FORM: how treeLookup's x index is computed — FORM_LITERAL the float formula as written; FORM_POW2 the exact-comparison form
+// for cell_count = 2^k (see tree_lookup_pow2); FORM_TABLE the same walk with per-cell thresholds for any other cell_count (the
+// reference's own 100000), see build_thresholds_kernel.
+template <bool COUNT, int FORM, int DEPTH = 0, bool RESIDENT = false, bool SAFEV = false, bool FULL = false, bool UNIT = false, bool BRICK = false>
 __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
+  constexpr bool POW2 = FORM != FORM_LITERAL;        // the exact forms (integer digits, one-compare box test)
   __shared__ __attribute__((aligned(16))) uint16_t s_nodes[(BRICK ? kBrickLdsCells : kLdsCells) * 8 + 8];   // + the sentinel slot (BRICK: the host stages no more than fit)
   for (uint32_t i = threadIdx.x * 8u; i < P.lds_nodes; i += (uint32_t)TDT_BLOCK * 8u)      // one cell (8 x u16) per lane and trip
     *reinterpret_cast<uint4 *>(&s_nodes[i]) = *reinterpret_cast<const uint4 *>(&P.packed[i]);
@@ -83,11 +84,20 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   if (threadIdx.x < 16 && P.lds_nodes + threadIdx.x < ((P.lds_nodes + 7u) & ~7u) + 8u)
     s_nodes[P.lds_nodes + threadIdx.x] = (uint16_t)((RESIDENT && POW2) ? 0u : kPackedEscape);
   __syncthreads();
+  constexpr bool TABLE = FORM == FORM_TABLE;
+  static_assert(!TABLE || (RESIDENT && SAFEV && !BRICK && !FULL), "per-cell thresholds: trees inside the LDS table");
+  __shared__ __attribute__((aligned(8))) float2 s_thr[TABLE ? kLdsCells + 1 : 1];      // FORM_TABLE: x_thresholds of the cells PARENT nodes point at
+  __shared__ uint32_t s_band;
+  if (TABLE) {
+    for (uint32_t i = threadIdx.x; i <= kLdsCells; i += (uint32_t)TDT_BLOCK)
+      s_thr[i] = i < P.thr_cells ? reinterpret_cast<const float2 *>(P.thr)[i] : make_float2(2.0f, 2.0f);
+    __syncthreads();
+  }
   constexpr int GL = RESIDENT ? 4 : 5;                                 // levels of the top-level jump table (see Grid<GL>)
   constexpr bool kUseGrid = !FULL && !BRICK && !COUNT && POW2 && SAFEV && DEPTH >= GL;   // see build_top_grid (FULL: the whole-depth table in global memory instead; BRICK: the 32-bit table below)
   __shared__ typename Grid<GL>::Entry s_grid[kUseGrid ? Grid<GL>::kEntries : 1];
   __shared__ int s_grid_ok;
-  if (kUseGrid) build_top_grid<GL>(s_nodes, P.lds_nodes, DEPTH, s_grid, &s_grid_ok);
+  if (kUseGrid) build_top_grid<GL, TABLE>(s_nodes, P.lds_nodes, DEPTH, s_grid, &s_grid_ok, s_thr, P.thr_cells, P.thr_f0max, &s_band);
   __shared__ __attribute__((aligned(16))) uint32_t s_grid32[BRICK ? (1 << 15) : 4];     // BRICK: build_bricks_kernel's table, copied as it is
   if (BRICK) {
     for (uint32_t i = threadIdx.x * 4u; i < (1u << 15); i += (uint32_t)TDT_BLOCK * 4u)
@@ -97,7 +107,8 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   NodeSource ns;
   ns.lds = s_nodes; ns.lds_nodes = P.lds_nodes; ns.lds_cells = (P.lds_nodes + 7u) >> 3;
   ns.grid = s_grid; ns.grid_ok = kUseGrid ? (__builtin_amdgcn_readfirstlane(s_grid_ok) != 0) : false;
-  ns.grid_band = FULL ? Grid<5>::kBand : (ns.grid_ok ? Grid<GL>::kBand : 2.0f);
+  ns.grid_band = FULL ? Grid<5>::kBand : (ns.grid_ok ? (TABLE && kUseGrid ? __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)s_band)) : Grid<GL>::kBand) : 2.0f);
+  ns.thr = s_thr; ns.thr_f0max = P.thr_f0max;
   ns.full = P.full_grid;
   ns.grid32 = s_grid32; ns.bricks = P.bricks;
   ns.cells = __builtin_amdgcn_make_buffer_rsrc((void *)P.cells, 0, (int)((P.cells_dwords >> 1) << 3), 0x00020000);
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       if (inside) {
         float ugx, ugy, ugz; uint32_t value;
         if (COUNT) cnt.iterations++;
-        const bool leaf = POW2 ? tree_lookup_pow2<COUNT, kMemoLevels, DEPTH, RESIDENT, SAFEV, FULL, BRICK>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, memo, cnt)
+        const bool leaf = POW2 ? tree_lookup_pow2<COUNT, kMemoLevels, DEPTH, RESIDENT, SAFEV, FULL, BRICK, TABLE>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, memo, cnt)
                                : tree_lookup<COUNT>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, cnt);
         lane_work += kCostStep + (127u - (__float_as_uint(inv_pow_depth) >> 23));   // + tree levels visited (inv_pow_depth = 2^-levels)
         const float bx = (UNIT ? ugx : ugx * P.scale) + P.min_x, by = (UNIT ? ugy : ugy * P.scale) + P.min_y, bz = (UNIT ? ugz : ugz * P.scale) + P.min_z;
@@ -443,20 +454,57 @@ __global__ __launch_bounds__(256) void pack_cells_kernel(const uint32_t *__restr
   packed[i] = (uint16_t)((value <= kPackedMaxValue) ? ((value << 2) | code) : kPackedEscape);
 }
 
-// One pass over the whole cells payload: out[0] = largest PARENT value (used as a cell index),
-// out[1] = largest value of any node.  Lets the host pick the specialised lookups (SAFEV / RESIDENT).
+// One pass over the whole cells payload: out[0] = largest PARENT value (used as a cell index), out[1] = largest value of any
+// node, out[2] = one past the last node that is not all zeros (a host that pre-allocates its cell buffer — the reference does,
+// main.rs:339-341 — leaves a tail of zero nodes, which read exactly as nodes past the end of the buffer do: EMPTY, value 0).
+// Lets the host pick the specialised lookups (SAFEV / RESIDENT).
 __global__ __launch_bounds__(256) void scan_cells_kernel(const uint32_t *__restrict__ cells, uint32_t n_nodes, uint32_t *__restrict__ out) {
-  uint32_t mp = 0, ma = 0;
+  uint32_t mp = 0, ma = 0, live = 0;
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_nodes; i += gridDim.x * 256u) {
     const uint2 n = *reinterpret_cast<const uint2 *>(cells + 2u * (size_t)i);
     ma = n.x > ma ? n.x : ma;
     if (n.y != 0u && n.y != 2u) mp = n.x > mp ? n.x : mp;
+    if ((n.x | n.y) != 0u) live = i + 1u;
   }
   for (int o = 32; o > 0; o >>= 1) {
-    uint32_t a = (uint32_t)__shfl_xor((int)mp, o, 64), b = (uint32_t)__shfl_xor((int)ma, o, 64);
-    mp = a > mp ? a : mp; ma = b > ma ? b : ma;
+    uint32_t a = (uint32_t)__shfl_xor((int)mp, o, 64), b = (uint32_t)__shfl_xor((int)ma, o, 64), c = (uint32_t)__shfl_xor((int)live, o, 64);
+    mp = a > mp ? a : mp; ma = b > ma ? b : ma; live = c > live ? c : live;
   }
-  if ((threadIdx.x & 63) == 0) { atomicMax(&out[0], mp); atomicMax(&out[1], ma); }
+  if ((threadIdx.x & 63) == 0) { atomicMax(&out[0], mp); atomicMax(&out[1], ma); atomicMax(&out[2], live); }
+}
+
+// FORM_TABLE builds: (F1, F2) of every cell index below n and, in aux[1], the bits of the largest F0 (see x_thresholds in
+// trace_device.hpp); aux[0] != 0 when some cell's x index is not of the three-threshold shape (then the literal kernel runs).
+// all != nullptr: the three thresholds of every cell, for the exhaustive check.  Once per (cell_count, inv_cell_count, n).
+__global__ __launch_bounds__(256) void build_thresholds_kernel(float inv_cell_count, int32_t cell_count, uint32_t n, float2 *__restrict__ thr, uint32_t *__restrict__ aux,
+                                                               float4 *__restrict__ all) {
+  const uint32_t v = blockIdx.x * 256u + threadIdx.x;
+  if (v >= n) return;
+  const float4 F = x_thresholds(v, inv_cell_count, cell_count, &aux[0]);
+  if (thr) thr[v] = make_float2(F.x, F.y);
+  if (all) all[v] = F;
+  atomicMax(&aux[1], __float_as_uint(F.z));              // (non-negative floats order as their bit patterns)
+}
+
+// Exhaustive check of x_thresholds' claim for one cell_count: for every cell index v < n_cells and EVERY f in [0, 1) the literal
+// formula's index equals 2v - 1 + (f >= F0(v)) + (f >= F1(v)) + (f >= F2(v)).  shift != 0 checks the harness: thresholds moved by
+// that many ulps must fail.  (v in the grid's y dimension, f bit patterns grid-strided in x.)
+__global__ __launch_bounds__(256) void selftest_index_kernel(float inv_cell_count, int32_t cell_count, const float4 *__restrict__ thr, int shift,
+                                                             unsigned long long *mismatches) {
+  const uint32_t v = blockIdx.y;
+  const float two_cc = (float)(int32_t)((uint32_t)cell_count << 1);
+  float4 F = thr[v];
+  if (shift) { F.x = __uint_as_float(__float_as_uint(F.x) + (uint32_t)shift); F.y = __uint_as_float(__float_as_uint(F.y) + (uint32_t)shift);
+               if (F.z != 0.0f) F.z = __uint_as_float(__float_as_uint(F.z) + (uint32_t)shift); }
+  unsigned long long bad = 0;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < 0x3F800000u; i += gridDim.x * 256u) {
+    const float f = __uint_as_float(i);
+    const int32_t lit = x_index_literal(v, f, inv_cell_count, two_cc);
+    const int32_t tab = (int32_t)(2u * v) - 1 + (f >= F.z ? 1 : 0) + (f >= F.x ? 1 : 0) + (f >= F.y ? 1 : 0);
+    bad += lit != tab ? 1u : 0u;
+  }
+  for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor((long long)bad, o, 64);
+  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(mismatches, bad);
 }
 
 // The whole-depth table of FULL builds (see tree_lookup_pow2): entry (x, y, z digits of a finest-level voxel position) = what
@@ -926,6 +974,38 @@ void make_sig(const tdt_ctx *ctx, const tdt_compute *c, const Cover &k, const td
     if (ctx->ssbo[sl]) { sig->slot[sl].buffer = ctx->ssbo[sl]; sig->slot[sl].version = ctx->ssbo[sl]->version; }
 }
 
+// The scene-specialised builds of the trace kernel (all SAFEV, COUNT = false), looked up by what the dispatch found out about the
+// scene.  One row per instantiation; a build that is not listed does not exist, and launch() falls back to the general kernel.
+using TraceFn = void (*)(const TraceParams);
+struct TraceVariant { int form, depth; bool resident, full, brick, unit; TraceFn fn; };
+#define TDT_V1(FORM, D, R, F, B, U) {tdt::FORM, D, R, F, B, U, tdt::trace_kernel<false, tdt::FORM, D, R, true, F, U, B>}
+#define TDT_V(FORM, D, R, F, B) TDT_V1(FORM, D, R, F, B, false), TDT_V1(FORM, D, R, F, B, true)
+const TraceVariant kTraceVariants[] = {
+  // trees outside the LDS table, depth 6-10: the 32-bit level-5 table with per-position bands (+ bricks for depths 6-9) ...
+  TDT_V(FORM_POW2, 6, false, false, true), TDT_V(FORM_POW2, 7, false, false, true), TDT_V(FORM_POW2, 8, false, false, true),
+  TDT_V(FORM_POW2, 9, false, false, true), TDT_V(FORM_POW2, 10, false, false, true),
+  // ... or, when that table cannot be built for the tree (or is switched off), the 16-bit 5-level table built per block and the memo walk
+  TDT_V(FORM_POW2, 6, false, false, false), TDT_V(FORM_POW2, 7, false, false, false), TDT_V(FORM_POW2, 8, false, false, false),
+  TDT_V(FORM_POW2, 9, false, false, false), TDT_V(FORM_POW2, 10, false, false, false),
+  // small trees inside the LDS table: the whole-depth table
+  TDT_V(FORM_POW2, 5, true, true, false), TDT_V(FORM_POW2, 6, true, true, false),
+  // trees inside the LDS table: 4-level jump table (depth >= 4) + whole-cell LDS reads
+  TDT_V(FORM_POW2, 3, true, false, false), TDT_V(FORM_POW2, 4, true, false, false), TDT_V(FORM_POW2, 5, true, false, false),
+  TDT_V(FORM_POW2, 6, true, false, false), TDT_V(FORM_POW2, 7, true, false, false), TDT_V(FORM_POW2, 8, true, false, false),
+  TDT_V(FORM_POW2, 9, true, false, false), TDT_V(FORM_POW2, 10, true, false, false),
+  // the same for a cell_count that is not a power of two (per-cell thresholds, the band of the jump table computed from them)
+  TDT_V(FORM_TABLE, 3, true, false, false), TDT_V(FORM_TABLE, 4, true, false, false), TDT_V(FORM_TABLE, 5, true, false, false),
+  TDT_V(FORM_TABLE, 6, true, false, false), TDT_V(FORM_TABLE, 7, true, false, false), TDT_V(FORM_TABLE, 8, true, false, false),
+  TDT_V(FORM_TABLE, 9, true, false, false), TDT_V(FORM_TABLE, 10, true, false, false),
+};
+#undef TDT_V
+#undef TDT_V1
+TraceFn find_variant(int form, int depth, bool resident, bool full, bool brick, bool unit) {
+  for (const TraceVariant &v : kTraceVariants)
+    if (v.form == form && v.depth == depth && v.resident == resident && v.full == full && v.brick == brick && v.unit == unit) return v.fn;
+  return nullptr;
+}
+
 int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_begin, int spp_count, void *carry,
            int total_spp, unsigned long long *counts_out) {
   tdt_ctx *ctx = c->ctx;
@@ -1004,8 +1084,8 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     if (!ctx->queue) TDT_HIP(ctx, hipMalloc((void **)&ctx->queue, sizeof(unsigned int)));
     P.lds_nodes = buf_nodes < tdt::kLdsCells * 8u ? (buf_nodes & ~7u) : tdt::kLdsCells * 8u;
     if (ctx->packed_of != cb || ctx->packed_version != cb->version) {
-      if (!ctx->scan) TDT_HIP(ctx, hipMalloc((void **)&ctx->scan, 2 * sizeof(uint32_t)));
-      TDT_HIP(ctx, hipMemsetAsync(ctx->scan, 0, 2 * sizeof(uint32_t), ctx->stream));
+      if (!ctx->scan) TDT_HIP(ctx, hipMalloc((void **)&ctx->scan, 4 * sizeof(uint32_t)));
+      TDT_HIP(ctx, hipMemsetAsync(ctx->scan, 0, 4 * sizeof(uint32_t), ctx->stream));
       if (P.lds_nodes)
         hipLaunchKernelGGL(tdt::pack_cells_kernel, dim3((P.lds_nodes + 255) / 256), dim3(256), 0, ctx->stream,
                            P.cells, P.cells_dwords, ctx->packed, P.lds_nodes);
@@ -1014,10 +1094,10 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
         hipLaunchKernelGGL(tdt::scan_cells_kernel, dim3(nb), dim3(256), 0, ctx->stream, P.cells, buf_nodes, ctx->scan);
       }
       TDT_HIP(ctx, hipGetLastError());
-      uint32_t res[2] = {0, 0};
+      uint32_t res[3] = {0, 0, 0};
       TDT_HIP(ctx, hipMemcpyAsync(res, ctx->scan, sizeof res, hipMemcpyDeviceToHost, ctx->stream));
       TDT_HIP(ctx, hipStreamSynchronize(ctx->stream));    // once per cells buffer (version), not per frame
-      ctx->max_parent_value = res[0]; ctx->max_any_value = res[1];
+      ctx->max_parent_value = res[0]; ctx->max_any_value = res[1]; ctx->live_nodes = res[2];
       ctx->packed_of = cb; ctx->packed_version = cb->version;
     }
     P.packed = ctx->packed; P.queue = ctx->queue;
@@ -1086,13 +1166,38 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     dim3 grid(nblk, 1, 1), block(TDT_BLOCK, 1, 1), grid4((unsigned)t.owned * 4u, 1, 1), block4(256, 1, 1);
     // the exact-comparison form of treeLookup needs cell_count = 2^k <= 2^22 and inv_cell_count = 2^-k
     // bit-for-bit (true for every scene Octree::init_global_buffers builds from such a count,
-    // octree.rs:49); anything else (e.g. the demo scene's 100000) takes the literal float form
+    // octree.rs:49); any other count (the reference's own 100000, main.rs:459) takes the per-cell threshold form when the tree
+    // sits in the LDS table (FORM_TABLE, below), else the literal float form
     const uint32_t cc = (uint32_t)P.cell_count;
+    const bool depth_ok = P.max_depth >= 0 && P.max_depth <= 30;
     const bool pow2 = !ctx->force_generic && P.cell_count > 0 && (cc & (cc - 1)) == 0 && cc <= (1u << 22) &&
-                      P.inv_cell_count == 1.0f / (float)cc && P.max_depth >= 0 && P.max_depth <= 30;
+                      P.inv_cell_count == 1.0f / (float)cc && depth_ok;
     // scene-property specialisations of the hot kernel (see tree_lookup_pow2); every variant is bit-identical
     const bool safev = ctx->max_parent_value < (1u << 22);
-    const bool resident = buf_nodes == P.lds_nodes && buf_nodes > 0 && (P.cells_dwords & 1u) == 0 && ctx->max_any_value <= tdt::kPackedMaxValue;
+    // resident: every node that is not all zeros sits in the LDS table (a pre-allocated buffer's tail of zero nodes reads as the
+    // table's all-EMPTY sentinel cell does, and as nodes past the end of the buffer do) and fits its 16-bit entries
+    const bool resident = buf_nodes > 0 && ctx->live_nodes <= P.lds_nodes && ctx->max_any_value <= tdt::kPackedMaxValue;
+    // FORM_TABLE: thresholds for every cell of the LDS table, built once per (cell_count, inv_cell_count, cells)
+    bool table_form = false;
+    if (mode != 2 && !counts_out && !pow2 && !ctx->force_generic && !ctx->no_specialise && !ctx->no_table_form && depth_ok && P.cell_count > 0 && resident) {
+      const uint32_t n_thr = (P.lds_nodes + 7u) >> 3;
+      uint32_t ic_bits; std::memcpy(&ic_bits, &P.inv_cell_count, 4);
+      if (ctx->thr_cc != P.cell_count || ctx->thr_ic_bits != ic_bits || ctx->thr_n != n_thr || !ctx->thr) {
+        if (!ctx->thr) TDT_HIP(ctx, hipMalloc((void **)&ctx->thr, ((size_t)tdt::kLdsCells + 1) * 2 * sizeof(float)));
+        uint32_t *aux = reinterpret_cast<uint32_t *>(ctx->thr + (size_t)tdt::kLdsCells * 2);      // {shape flag, bits of F0max}
+        TDT_HIP(ctx, hipMemsetAsync(aux, 0, 2 * sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(tdt::build_thresholds_kernel, dim3((n_thr + 255u) / 256u), dim3(256), 0, ctx->stream, P.inv_cell_count, P.cell_count, n_thr,
+                           reinterpret_cast<float2 *>(ctx->thr), aux, (float4 *)nullptr);
+        TDT_HIP(ctx, hipGetLastError());
+        uint32_t res[2] = {1, 0};
+        TDT_HIP(ctx, hipMemcpyAsync(res, aux, sizeof res, hipMemcpyDeviceToHost, ctx->stream));
+        TDT_HIP(ctx, hipStreamSynchronize(ctx->stream));    // once per octree-uniform change, not per frame
+        ctx->thr_cc = P.cell_count; ctx->thr_ic_bits = ic_bits; ctx->thr_n = n_thr; ctx->thr_ok = res[0] == 0;
+        std::memcpy(&ctx->thr_f0max, &res[1], 4);
+      }
+      table_form = ctx->thr_ok && ctx->max_parent_value < n_thr;      // every cell index an x decision can meet has its thresholds
+      P.thr = ctx->thr; P.thr_cells = n_thr; P.thr_f0max = ctx->thr_f0max;
+    }
     bool launched = false;
     P.accumulate = mode == 1 ? 1 : 0;
     // small resident trees: the whole-depth lookup table (tree_lookup_pow2 FULL), built once per cells buffer
@@ -1153,37 +1258,22 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
         if (P.lds_nodes > tdt::kBrickLdsCells * 8u) P.lds_nodes = tdt::kBrickLdsCells * 8u;      // (the BRICK builds' LDS node table)
       }
     }
-    if (mode != 2 && !counts_out && pow2 && safev && !ctx->no_specialise) {
-      const bool unit = P.scale == 1.0f && P.inv_scale == 1.0f;          // x * 1.0f is x: the UNIT builds do not multiply
-#define TDT_BRICK1(D, U) if (ctx->probe_launch) hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, false, true, true, false, U, true>), grid, block, 0, ctx->stream, P); \
-                         else hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, false, true, false, false, U, true>), grid, block, 0, ctx->stream, P)
-      if (brick) switch (P.max_depth) {
-#define TDT_BRICK2(D) case D: if (unit) TDT_BRICK1(D, true); else TDT_BRICK1(D, false); launched = true; break
-        TDT_BRICK2(6); TDT_BRICK2(7); TDT_BRICK2(8); TDT_BRICK2(9); TDT_BRICK2(10);
-#undef TDT_BRICK2
-        default: break; }
-#undef TDT_BRICK1
-#define TDT_SPEC4(D, R, F, U) if (ctx->probe_launch) hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, R, true, true, F, U>), grid, block, 0, ctx->stream, P); \
-                              else hipLaunchKernelGGL((tdt::trace_kernel<false, true, D, R, true, false, F, U>), grid, block, 0, ctx->stream, P)
-#define TDT_SPEC(D, R) if (unit) TDT_SPEC4(D, R, false, true); else TDT_SPEC4(D, R, false, false); launched = true; break
-#define TDT_SPEC_FULL(D) if (unit) TDT_SPEC4(D, true, true, true); else TDT_SPEC4(D, true, true, false); launched = true; break
-      if (launched) {}
-      else if (full) switch (P.max_depth) { case 5: TDT_SPEC_FULL(5); case 6: TDT_SPEC_FULL(6); default: break; }
-      else
-      if (resident) switch (P.max_depth) {
-        case 3: TDT_SPEC(3, true); case 4: TDT_SPEC(4, true); case 5: TDT_SPEC(5, true); case 6: TDT_SPEC(6, true);
-        case 7: TDT_SPEC(7, true); default: break; }
-      else switch (P.max_depth) {
-        case 6: TDT_SPEC(6, false); case 7: TDT_SPEC(7, false); case 8: TDT_SPEC(8, false); case 9: TDT_SPEC(9, false);
-        case 10: TDT_SPEC(10, false); default: break; }
-#undef TDT_SPEC
-#undef TDT_SPEC_FULL
-#undef TDT_SPEC4
+    if (mode != 2 && !counts_out && (pow2 || table_form) && safev && !ctx->no_specialise) {
+      // UNIT builds do not multiply by a scale of exactly 1.0f (x * 1.0f is x).  The probe launch of a two-phase frame runs the build
+      // that multiplies — the same bits, and the short launch then has a row of its own in profiler statistics instead of halving the
+      // average of the launches that do the work
+      const bool unit = P.scale == 1.0f && P.inv_scale == 1.0f && !ctx->probe_launch;
+      const int form = pow2 ? tdt::FORM_POW2 : tdt::FORM_TABLE;
+      TraceFn fn = nullptr;
+      if (brick) fn = find_variant(form, P.max_depth, false, false, true, unit);
+      if (!fn && full) fn = find_variant(form, P.max_depth, true, true, false, unit);
+      if (!fn) fn = find_variant(form, P.max_depth, resident, false, false, unit);
+      if (fn) { hipLaunchKernelGGL(fn, grid, block, 0, ctx->stream, P); launched = true; }
     }
-#define TDT_LAUNCH(C) do { if (pow2) hipLaunchKernelGGL((tdt::trace_kernel<C, true>), grid, block, 0, ctx->stream, P); \
-                           else hipLaunchKernelGGL((tdt::trace_kernel<C, false>), grid, block, 0, ctx->stream, P); } while (0)
+#define TDT_LAUNCH(C) do { if (pow2) hipLaunchKernelGGL((tdt::trace_kernel<C, tdt::FORM_POW2>), grid, block, 0, ctx->stream, P); \
+                           else hipLaunchKernelGGL((tdt::trace_kernel<C, tdt::FORM_LITERAL>), grid, block, 0, ctx->stream, P); } while (0)
     if (!launched && counts_out && getenv("TDT_COUNT_SPECIALISED") && pow2 && safev && resident && P.max_depth == 6) {
-      hipLaunchKernelGGL((tdt::trace_kernel<true, true, 6, true, true>), grid, block, 0, ctx->stream, P); launched = true;   // diagnostics: region timers of the specialised form
+      hipLaunchKernelGGL((tdt::trace_kernel<true, tdt::FORM_POW2, 6, true, true>), grid, block, 0, ctx->stream, P); launched = true;   // diagnostics: region timers of the specialised form
     }
     if (launched) {}
     else if (mode != 2 && !counts_out) TDT_LAUNCH(false);
@@ -1242,11 +1332,13 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
     ctx->no_cost_accum = getenv("TDT_NO_COST_ACCUM") != nullptr;
     ctx->no_two_phase = getenv("TDT_NO_TWO_PHASE") != nullptr;
     ctx->no_full = getenv("TDT_NO_FULL_GRID") != nullptr;
+    ctx->no_table_form = getenv("TDT_NO_TABLE_FORM") != nullptr;
     ctx->no_bricks = getenv("TDT_NO_BRICKS") != nullptr;
     const char *ms = getenv("TDT_MAX_SHARE"); ctx->max_share = ms ? (float)atof(ms) : 1.0f;
     const char *ob = getenv("TDT_ORDER_BLEND"); ctx->order_blend = ob ? (float)atof(ob) : 0.5f;
     const char *pd = getenv("TDT_PROBE_DIV"); ctx->probe_div = pd && atoi(pd) >= 2 && atoi(pd) <= 64 ? atoi(pd) : 16; }
-  ctx->scan = nullptr; ctx->max_parent_value = ctx->max_any_value = 0xFFFFFFFFu;
+  ctx->scan = nullptr; ctx->max_parent_value = ctx->max_any_value = ctx->live_nodes = 0xFFFFFFFFu;
+  ctx->thr = nullptr; ctx->thr_cc = 0; ctx->thr_ic_bits = 0; ctx->thr_n = 0; ctx->thr_ok = false;
   { hipDeviceProp_t prop; ctx->num_cus = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
   { const char *fg = getenv("TDT_FORCE_GENERIC"); ctx->force_generic = fg && fg[0] == '1';
     const char *ns_ = getenv("TDT_NO_SPECIALISE"); ctx->no_specialise = ns_ && ns_[0] == '1';
@@ -1282,6 +1374,7 @@ void tdt_ctx_destroy(tdt_ctx *ctx) {
   if (ctx->present) (void)hipFree(ctx->present);
   if (ctx->frame_carry) (void)hipFree(ctx->frame_carry);
   if (ctx->full_grid) (void)hipFree(ctx->full_grid);
+  if (ctx->thr) (void)hipFree(ctx->thr);
   if (ctx->brick_grid) (void)hipFree(ctx->brick_grid);
   if (ctx->bricks) (void)hipFree(ctx->bricks);
   if (ctx->phase_timing) for (auto &e : ctx->phase_ev) (void)hipEventDestroy(e);
@@ -1622,17 +1715,17 @@ int tdt_set_partition(tdt_compute *c, int rank, int world) {
 
 int tdt_dispatch_accumulate(tdt_compute *c, int width, int height, int depth, int spp_begin, int spp_count, void *carry) {
   if (!c) return TDT_ERR_INVALID_VALUE;
-  if (c->ctx->multi) return fail(c->ctx, TDT_ERR_INVALID_OPERATION, "progressive passes are a single-device feature (per-device carry memory)");
   if (c->kind != TDT_PROGRAM_RAYTRACER) return fail(c->ctx, TDT_ERR_INVALID_OPERATION, "not the raytracer program");
   if (spp_begin < 0 || spp_count < 0) return fail(c->ctx, TDT_ERR_INVALID_VALUE, "negative sample range");
+  if (c->ctx->multi) return tdt::multi_dispatch_accumulate(c, width, height, depth, spp_begin, spp_count, carry);
   if (carry && ((uintptr_t)carry & 15) != 0) return fail(c->ctx, TDT_ERR_INVALID_VALUE, "carry memory must be 16-byte aligned");
   return launch(c, width, height, depth, 1, spp_begin, spp_count, carry, 0, nullptr);
 }
 
 int tdt_dispatch_resolve(tdt_compute *c, int width, int height, int depth, int total_spp) {
   if (!c) return TDT_ERR_INVALID_VALUE;
-  if (c->ctx->multi) return fail(c->ctx, TDT_ERR_INVALID_OPERATION, "progressive passes are a single-device feature (per-device carry memory)");
   if (c->kind != TDT_PROGRAM_RAYTRACER) return fail(c->ctx, TDT_ERR_INVALID_OPERATION, "not the raytracer program");
+  if (c->ctx->multi) return tdt::multi_dispatch_resolve(c, width, height, depth, total_spp);
   return launch(c, width, height, depth, 2, 0, 0, nullptr, total_spp, nullptr);
 }
 
@@ -1730,6 +1823,33 @@ int tdt_selftest(tdt_ctx *ctx, int which, uint64_t *mismatches) {
   TDT_HIP(ctx, hipGetLastError());
   TDT_HIP(ctx, hipMemcpyAsync(mismatches, ctx->counters, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   TDT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return TDT_OK;
+}
+
+/* Exhaustive check of the per-cell x-index thresholds (FORM_TABLE builds, x_thresholds in trace_device.hpp) for one cell_count:
+ * every f in [0,1) x every cell index below n_cells against the literal formula.  *shape_ok = 0 when some cell's index is not of the
+ * two-threshold shape (such a scene runs the literal kernel); shift != 0 moves the thresholds by that many ulps (the harness:
+ * must report mismatches). */
+int tdt_selftest_index(tdt_ctx *ctx, int32_t cell_count, float inv_cell_count, uint32_t n_cells, int shift, uint64_t *mismatches, int *shape_ok) {
+  if (!ctx || !mismatches || !shape_ok || n_cells == 0 || n_cells > 65535u) return TDT_ERR_INVALID_VALUE;
+  if (ctx->multi) ctx = tdt::multi_first_member(ctx);
+  TDT_HIP(ctx, hipSetDevice(ctx->device));
+  float4 *thr = nullptr;
+  TDT_HIP(ctx, hipMalloc((void **)&thr, (size_t)n_cells * sizeof(float4) + 16));
+  unsigned long long *cnt = reinterpret_cast<unsigned long long *>(thr + n_cells);
+  uint32_t *aux = reinterpret_cast<uint32_t *>(cnt + 1);
+  hipError_t e = hipMemsetAsync(cnt, 0, 16, ctx->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(tdt::build_thresholds_kernel, dim3((n_cells + 255u) / 256u), dim3(256), 0, ctx->stream, inv_cell_count, cell_count, n_cells, (float2 *)nullptr, aux, thr);
+    hipLaunchKernelGGL(tdt::selftest_index_kernel, dim3(512, n_cells), dim3(256), 0, ctx->stream, inv_cell_count, cell_count, thr, shift, cnt);
+    e = hipGetLastError();
+  }
+  unsigned long long host[2] = {0, 0};
+  if (e == hipSuccess) e = hipMemcpyAsync(host, cnt, 16, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(thr);
+  if (e != hipSuccess) return hip_fail(ctx, e, "tdt_selftest_index");
+  *mismatches = host[0]; *shape_ok = (uint32_t)host[1] == 0u ? 1 : 0;
   return TDT_OK;
 }
 

@@ -16,6 +16,10 @@ namespace tdt {
 
 #define TDT_DEV __device__ __forceinline__
 
+// how a kernel build computes treeLookup's x index (rc:376-378): the float formula as written; the exact-comparison form for
+// cell_count = 2^k (tree_lookup_pow2); the same walk with per-cell thresholds for any other cell_count (XThreshold)
+enum : int { FORM_LITERAL = 0, FORM_POW2 = 1, FORM_TABLE = 2 };
+
 TDT_DEV float f_fract(float x) { return x - __builtin_floorf(x); }
 // for x >= 0 the v_fract_f32 instruction returns exactly x - floor(x) (checked on all inputs by
 // tdt_selftest mode 4); negative arguments keep the two-instruction form (they differ: fract(-tiny) = 1.0)
@@ -181,6 +185,7 @@ struct NodeSource {
   bool grid_ok; float grid_band;                      // grid_band = kGridBand, or 2 when the table is unusable
   const uint16_t *full;                               // FULL builds: the whole-depth table in global memory (see tree_lookup_pow2)
   const uint32_t *grid32; const void *bricks;         // BRICK builds: the 5-level table with brick headers (LDS) and the bricks (global memory, 16-bit entries)
+  const float2 *thr; float thr_f0max;                 // FORM_TABLE builds: (F1, F2) per cell (LDS) and the scene-wide bound on F0, see x_thresholds
   __amdgpu_buffer_rsrc_t cells;                       // raw buffer over the cells payload (8-byte granules)
 };
 
@@ -317,6 +322,55 @@ TDT_DEV bool tree_lookup(const TraceParams &P, const NodeSource &ns, float cx, f
   return is_leaf;
 }
 
+// ---- treeLookup's x index for ANY cell_count (FORM_TABLE) ------------------------------------------------------------------
+// The x index of a level, as compiled (rc:376-378):
+//     ix(v, f) = int(round_even(((float(v) + f) * inv_cell_count) * float(2 * cell_count) + -0.5))
+// is, for a fixed cell index v, a composition of monotone roundings of f, hence a non-decreasing step function of the level's
+// coordinate f in [0, 1).  With a power-of-two cell_count the products are exact and the steps are tree_lookup_pow2's q > 0.5 /
+// q == 1 tests.  With the reference's own 100000 (main.rs:459: fl(1e-5) * 200000 = 2 (1 - 2.5e-8)) they sit within an ulp or two
+// of 1/2 and 1, differently for every v — and for many v (7, 11, 14, 15, ... : a third of all cells) the products fall short at the
+// bottom of the cell as well: ix(v, f) = 2v - 1, the upper half of the PREVIOUS cell, for f below half an ulp of v.  The
+// reference really reads that node there, so this kernel must too.  Wherever ix(v, 0) is 2v - 1 or 2v and ix(v, 1 - 2^-24) is
+// 2v + 1 or 2v + 2 (checked per cell when the table is built, never assumed) the function is fully described by three thresholds
+//     ix(v, f) = 2v - 1 + (f >= F0(v)) + (f >= F1(v)) + (f >= F2(v)),    F0 <= F1 <= F2, F0 = 0: never 2v - 1, F2 = 2: never 2v + 2
+// which build_thresholds_kernel finds by bisection over the bit patterns of f, evaluating the literal formula.  No closed form,
+// so a table: (F1, F2), 8 bytes per cell, read beside the cell's nodes — two compares on f itself, not even the addition the
+// power-of-two form does — and ONE scene-wide bound F0max = max F0(v) (about half an ulp of the largest cell index: 1e-7 ... 1e-4)
+// below which a lane evaluates the literal formula for that level (a wave-uniform, rare branch, like the 2v + 2 case).  The band
+// a jump table needs around the integers of 2^L c is exact as well: the decision of level l on cell v differs from the
+// coordinate's binary digit only for f between 1/2 and F1(v), is 2v + 2 only for f >= F2(v) and 2v - 1 only for f < F0(v), i.e.
+//     need_l(v) = 2^(L - l + 1) max(|F1(v) - 1/2|, 1 - F2(v), F0max)                      (the differences are exact in fp32)
+// and a lane is on the table's side whenever |2^L c - rint(2^L c)| > the largest need along its descent (build_top_grid computes
+// the largest over the whole table: one band per scene).  The claim "thresholds == literal formula" is checked exhaustively —
+// every f in [0,1) x every cell — by tdt_selftest_index (tests/test_gpu_table_form.py).
+TDT_DEV int32_t x_index_literal(uint32_t v, float f, float inv_cell_count, float two_cc) {
+  return f2i(__builtin_rintf((((float)v + f) * inv_cell_count) * two_cc + -0.5f));
+}
+TDT_DEV float x_threshold_need(float2 F, float f0max) {  // how far from 1/2, 1 and 0 the decisions of this cell leave the binary digit
+  const float d1 = __builtin_fabsf(F.x - 0.5f), d2 = F.y <= 1.0f ? 1.0f - F.y : 0.0f;
+  const float d = d1 > d2 ? d1 : d2;
+  return d > f0max ? d : f0max;
+}
+// one cell's thresholds (x = F1, y = F2, z = F0); *bad is raised when ix(v, .) is not of the three-threshold shape
+TDT_DEV float4 x_thresholds(uint32_t v, float inv_cell_count, int32_t cell_count, uint32_t *bad) {
+  const float two_cc = (float)(int32_t)((uint32_t)cell_count << 1);
+  const int32_t base = (int32_t)(2u * v);
+  const uint32_t kOne = 0x3F800000u;                   // f runs over the bit patterns [0, kOne): +0 ... 1 - 2^-24, in value order
+  const int32_t g0 = x_index_literal(v, 0.0f, inv_cell_count, two_cc), g1 = x_index_literal(v, __uint_as_float(kOne - 1u), inv_cell_count, two_cc);
+  if (v >= (1u << 22) || cell_count <= 0 || g0 < base - 1 || g0 > base || g1 < base + 1 || g1 > base + 2 || (v == 0u && g0 != 0)) {
+    atomicOr(bad, 1u);
+    return make_float4(2.0f, 2.0f, 0.0f, 0.0f);
+  }
+  auto first = [&](int32_t target) {                  // smallest f with ix(v, f) >= target
+    uint32_t lo = 0u, hi = kOne;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (x_index_literal(v, __uint_as_float(mid), inv_cell_count, two_cc) >= target) hi = mid; else lo = mid + 1u;
+    }
+    return lo == kOne ? 2.0f : __uint_as_float(lo);
+  };
+  return make_float4(first(base + 1), first(base + 2), first(base), 0.0f);
+}
 // Per-lane memo of the last node fetched from HBM/L2 at each of CL levels (levels kMemoFirst+1 ..
 // kMemoFirst+CL; shallower levels always sit in the LDS table).  The scene is read-only, so
 // "node idx at level l" fetched for the previous traversal step is still the node: consecutive
@@ -378,27 +432,35 @@ template <> struct Grid<5> {
     v = parent ? g >> 2 : g >> 5;
   }
 };
-template <int GL>
-TDT_DEV void build_top_grid(const uint16_t *lds, uint32_t lds_nodes, int depth, typename Grid<GL>::Entry *grid, int *grid_ok) {
+template <int GL, bool TABLE = false>
+TDT_DEV void build_top_grid(const uint16_t *lds, uint32_t lds_nodes, int depth, typename Grid<GL>::Entry *grid, int *grid_ok,
+                            const float2 *thr = nullptr, uint32_t thr_cells = 0u, float f0max = 0.0f, uint32_t *band_bits = nullptr) {
   constexpr int kGridLevels = GL;
-  if (threadIdx.x == 0) *grid_ok = depth >= kGridLevels ? 1 : 0;
+  if (threadIdx.x == 0) { *grid_ok = depth >= kGridLevels ? 1 : 0; if (TABLE) *band_bits = 0u; }
   __syncthreads();
   if (depth >= kGridLevels) {
     for (uint32_t e = threadIdx.x; e < Grid<GL>::kEntries; e += blockDim.x) {
       const uint32_t xg = e >> (2 * kGridLevels), yg = (e >> kGridLevels) & ((1u << kGridLevels) - 1u), zg = e & ((1u << kGridLevels) - 1u);
       uint32_t v = 0, code = 1u, m = 0;
       bool ok = true;
+      float need = 0.0f;
       for (int l = 1; l <= kGridLevels && code == 1u; l++) {
         const int sh = kGridLevels - l;
+        if (TABLE) {                                  // this level's x decision is made on cell v: see x_thresholds
+          if (v >= thr_cells) { ok = false; break; }
+          const float n = x_threshold_need(thr[v], f0max) * (float)(2 << sh);
+          need = n > need ? n : need;
+        }
         const uint32_t idx = ((2u * v + ((xg >> sh) & 1u)) << 2) + (((yg >> sh) & 1u) << 1) + ((zg >> sh) & 1u);
         const uint32_t n = lds[idx < lds_nodes ? idx : lds_nodes];
         if (n == kPackedEscape) { ok = false; break; }
         v = n >> 2; code = n & 3u; m = (uint32_t)l;
-        if (code == 1u && l < kGridLevels && v >= grid_v_bound(l)) ok = false;     // this v feeds the next level's x decision
+        if (!TABLE && code == 1u && l < kGridLevels && v >= grid_v_bound(l)) ok = false;     // this v feeds the next level's x decision
       }
       if (code == 1u && m < (uint32_t)kGridLevels) ok = false;     // (the descent was cut short by a table that is unusable anyway)
       if (!Grid<GL>::encode(v, m, code, grid[e])) ok = false;
       if (!ok) atomicAnd(grid_ok, 0);
+      if (TABLE) atomicMax(band_bits, __float_as_uint(need));     // (non-negative floats order as their bit patterns)
     }
   }
   __syncthreads();
@@ -462,9 +524,10 @@ constexpr uint32_t kBrickLdsCells = 1024u;            // BRICK builds keep a sma
 TDT_DEV int brick_band_exp(int l, uint32_t v) { return (v == 0u ? -40 : (31 - (int)__builtin_clz(v)) + 5 - l - 23); }
 // fl(v + f) - v for any integer v in [2^e, 2^(e+1)), e <= 21
 TDT_DEV float brick_q(uint32_t e, float f) { const float V = __uint_as_float((127u + e) << 23); return (V + f) - V; }
-template <bool COUNT, int CL, int DEPTH, bool RESIDENT, bool SAFEV, bool FULL = false, bool BRICK = false>
+template <bool COUNT, int CL, int DEPTH, bool RESIDENT, bool SAFEV, bool FULL = false, bool BRICK = false, bool TABLE = false>
 TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float fx, float fy, float fz, float &inv_pow_depth,
                               float &gx, float &gy, float &gz, uint32_t &value, NodeMemo<CL> &memo, Counters &cnt) {
+  static_assert(!TABLE || (RESIDENT && SAFEV && !BRICK), "per-cell thresholds: trees inside the LDS table");
   const int depth = DEPTH > 0 ? DEPTH : P.max_depth;
   const float scale_d = __uint_as_float((uint32_t)(127 + depth) << 23);     // 2^depth
   const float Yf = fy * scale_d, Zf = fz * scale_d;                        // exact
@@ -561,18 +624,25 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
       // past the table read the all-EMPTY sentinel cell (a read past the end of the buffer IS 0: robust access).
       const uint32_t cell = v < ns.lds_cells ? v : ns.lds_cells;
       const uint4 c = *reinterpret_cast<const uint4 *>(ns.lds + (cell << 3));
-      const float q = (fv + fx) - fv;
-      const bool a = q > 0.5f, b = (q == 1.0f);
-      qx = qx + qx + ((a && !b) ? 1u : 0u);
+      bool a, b, low = false;
+      if constexpr (TABLE) { const float2 F = ns.thr[cell]; a = fx >= F.x; b = fx >= F.y; low = fx < ns.thr_f0max; }       // (x_thresholds)
+      else { const float q = (fv + fx) - fv; a = q > 0.5f; b = (q == 1.0f); }
+      uint32_t bitx = (a && !b) ? 1u : 0u;
       const uint32_t yb = (Yi >> sh) & 1u, zb = (Zi >> sh) & 1u;
       const uint32_t lo = a ? c.z : c.x, hi = a ? c.w : c.y;
       uint32_t n = ((yb ? hi : lo) >> (zb << 4)) & 0xFFFFu;
-      if (__builtin_expect(__ballot(b) != 0ull, 0)) {    // q == 1: x index 2v + 2, the first half of the NEXT cell
-        if (b) {
-          const uint32_t idx = ((2u * v + 2u) << 2) + (yb << 1) + zb;
+      if (__builtin_expect(__ballot(b || low) != 0ull, 0)) {    // q == 1: x index 2v + 2, the first half of the NEXT cell
+        if (b || low) {
+          uint32_t ix = 2u * v + 2u;
+          if constexpr (TABLE) if (low) {                // f below the largest F0 of the scene: the formula itself (2v - 1 for f < F0(v))
+            ix = (uint32_t)x_index_literal(v, fx, P.inv_cell_count, (float)(int32_t)((uint32_t)P.cell_count << 1));
+            bitx = ix & 1u;
+          }
+          const uint32_t idx = ((ix << 2) + (yb << 1) + zb) & 0x1FFFFFFFu;
           n = ns.lds[idx < ns.lds_nodes ? idx : ns.lds_nodes];
         }
       }
+      qx = qx + qx + bitx;
       v = n >> 2; code = n & 3u;
       fx = f_fract_nonneg(fx0 * __uint_as_float((uint32_t)(127 + l) << 23));
       return;

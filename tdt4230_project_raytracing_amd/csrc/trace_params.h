@@ -29,6 +29,7 @@ struct TraceParams {
   uint32_t lds_nodes;           // number of nodes (8 per cell) staged in LDS by every block
   const uint16_t *full_grid;    // FULL builds: one entry per finest-level voxel position (8^max_depth), see build_full_grid_kernel
   const uint32_t *brick_grid;   // BRICK builds: the 5-level jump table with brick headers (32^3 x 32 bit), see build_bricks_kernel
+  const float *thr; uint32_t thr_cells; float thr_f0max;   // FORM_TABLE builds: (F1, F2) per cell index below thr_cells and the largest F0, see x_thresholds (trace_device.hpp)
   const void *bricks;           // BRICK builds: per level-5 position 27 x 64 (depth 8) or 81 x 256 (depth 9) 16-bit entries: what the levels below 5 end on, by decision sequence
   int32_t compact;             // 1: image is this rank's tile buffer [owned tile k][32][32] RGBA
   int32_t cover_w, cover_h;    // pixels a dispatch covers: min(32*groups, image size)

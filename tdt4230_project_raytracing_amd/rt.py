@@ -68,6 +68,8 @@ SYMBOLS = [
     ("tdt_debug_phase_timing", _I, [_P, _I, ctypes.POINTER(ctypes.c_float)]),
     ("tdt_debug_multi_timing", _I, [_P, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
     ("tdt_debug_multi_transport", ctypes.c_char_p, [_P]),
+    ("tdt_debug_multi_rccl_ranks", _I, [_P]),
+    ("tdt_debug_multi_fail", _I, [_P, _I]),
     ("tdt_octree_build_cells", _I, [_P, _P, _S, _I, _PP, ctypes.POINTER(ctypes.c_uint32)]),
     ("tdt_octree_build_from_points", _I, [_P, _P, _S, ctypes.POINTER(ctypes.c_int32), _P, _P, _S, _I, _I, _PP,
                                           ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
@@ -77,6 +79,7 @@ SYMBOLS = [
     ("tdt_debug_wave_ends", _I, [_P, ctypes.POINTER(ctypes.c_uint64), _I]),
     ("tdt_debug_pixel_log", _I, [_P, ctypes.c_void_p, ctypes.c_size_t]),
     ("tdt_selftest", _I, [_P, _I, ctypes.POINTER(ctypes.c_uint64)]),
+    ("tdt_selftest_index", _I, [_P, ctypes.c_int32, _F, ctypes.c_uint32, _I, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int)]),
 ]
 
 _lib = None
@@ -153,6 +156,14 @@ class Context:
     def multi_transport(self):
         return lib().tdt_debug_multi_transport(self.h).decode()
 
+    def multi_rccl_ranks(self):
+        """Ranks of the RCCL communicator a multi-device context created (0: none / copy transport)."""
+        return int(lib().tdt_debug_multi_rccl_ranks(self.h))
+
+    def multi_fail(self, member):
+        """Test hook: the next raytracer dispatch fails at device index `member` (after the devices before it were launched)."""
+        self.check(lib().tdt_debug_multi_fail(self.h, int(member)))
+
     def edit_mode(self, mode):
         """0: edits run in parallel when that is provably the ordered result; 1: always the ordered one-lane walk."""
         self.check(lib().tdt_debug_edit_mode(self.h, mode))
@@ -177,6 +188,12 @@ class Context:
         n = ctypes.c_uint64(0)
         self.check(lib().tdt_selftest(self.h, which, ctypes.byref(n)))
         return n.value
+
+    def selftest_index(self, cell_count, inv_cell_count, n_cells, shift=0):
+        """(mismatches, shape_ok) of the per-cell x-index thresholds vs the literal formula: every f in [0,1) x every cell < n_cells."""
+        n, ok = ctypes.c_uint64(0), ctypes.c_int(0)
+        self.check(lib().tdt_selftest_index(self.h, int(cell_count), float(inv_cell_count), int(n_cells), int(shift), ctypes.byref(n), ctypes.byref(ok)))
+        return n.value, bool(ok.value)
 
     def close(self):
         if self.h:

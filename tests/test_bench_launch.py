@@ -39,7 +39,27 @@ def test_self_launch_spawns_ranks_that_meet():
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
-    assert json.loads(lines[0]) == {"rendezvous": 3, "rank_sum": 3.0, "ranks_seen": 3}
+    j = json.loads(lines[0])
+    assert {k: j[k] for k in ("rendezvous", "rank_sum", "ranks_seen")} == {"rendezvous": 3, "rank_sum": 3.0, "ranks_seen": 3}
+    # the fields that make the N>1 strong line self-explaining, computed over the same process group: ranks "traced" 10/20/30 ms
+    st = j["strong"]
+    assert st["backend"] == "gloo" and st["ranks_seen"] == 3
+    assert st["imbalance"] == 1.5 and st["speedup_vs_1gpu"] == 2.0 and st["one_gpu_ms"] == 60.0
+
+
+def test_strong_summary_fields():
+    st = bench.strong_summary(100.0, [90.0, 100.0, 95.0, 99.0], 380.0, "rank 0 alone", "nccl", 4)
+    assert st["speedup_vs_1gpu"] == 3.8 and st["backend"] == "nccl" and st["ranks_seen"] == 4
+    assert abs(st["imbalance"] - 100.0 / 96.0) < 1e-3
+    one = bench.strong_summary(617.0, [617.0], 617.0, "this measurement (one rank)", "none (one rank: no collective)", 1)
+    assert one["speedup_vs_1gpu"] == 1.0 and one["imbalance"] == 1.0
+
+
+def test_physical_roofline_is_quoted_from_committed_counters():
+    p = bench.physical_roofline("config2_spp64_gpus1")
+    assert p and p["bound"] == "valu" and 0 < p["frac"] < 1 and abs(p["frac"] - p["issue_util"] * p["lane_util"]) < 1e-3
+    assert p["source"].startswith("profiles/")
+    assert bench.physical_roofline("no_such_workload") is None
 
 
 def test_a_failing_rank_fails_the_launch():
@@ -69,6 +89,7 @@ def test_bench_gpus_2_self_launched_on_one_gpu():
     assert len(j["config"]["trace_ms_per_rank"]) == 2 and j["config"]["gather_ms"] is not None
     s = j["strong"]
     assert s["image"] == [7680, 4320] and s["spp"] == 64 and s["written_pixels"] == 7680 * 4320 and len(s["trace_ms_per_rank"]) == 2
+    assert s["backend"] == "gloo" and s["ranks_seen"] == 2 and s["imbalance"] >= 1.0 and s["speedup_vs_1gpu"] > 0 and "rank 0 alone" in s["one_gpu_source"]
     sp = j["single_process"]
     assert "error" not in sp, sp
-    assert sp["devices"] == [0, 0] and sp["written_pixels"] == 7680 * 4320 and sp["transport"] == "copy"
+    assert sp["devices"] == [0, 0] and sp["written_pixels"] == 7680 * 4320 and sp["transport"] == "copy" and sp["rccl_ranks"] == 0

@@ -86,8 +86,11 @@ def test_multi_context_error_behaviour(frame):
         with pytest.raises(rt.TdtError) as e:
             r.shader.set_partition(0, 2)
         assert e.value.code == rt.ERR_INVALID_OPERATION
-        with pytest.raises(rt.TdtError) as e:
-            r.shader.dispatch_accumulate(64, 64, 1, 0, 1)
+        with pytest.raises(rt.TdtError) as e:                # a resolve with nothing accumulated
+            r.shader.dispatch_resolve(cam.image_width + 1, cam.image_height + 1, 1, 16)
+        assert e.value.code == rt.ERR_INVALID_OPERATION
+        with pytest.raises(rt.TdtError) as e:                # a pass that continues sums that do not exist
+            r.shader.dispatch_accumulate(cam.image_width + 1, cam.image_height + 1, 1, 4, 4)
         assert e.value.code == rt.ERR_INVALID_OPERATION
         counts = r.shader.dispatch_counted(cam.image_width + 1, cam.image_height + 1)
         one = rt.Renderer(scene, cam)
@@ -99,3 +102,68 @@ def test_multi_context_error_behaviour(frame):
         rt.Context(devices=[])
     with pytest.raises(rt.TdtError):
         rt.Context(devices=[0, 99])
+
+
+@pytest.mark.parametrize("devices,fail_at", [([0, 0, 0], 2), ([0, 0, 0], 0), ([0] * 5, 3)])
+def test_half_launched_frame_is_drained_and_the_next_frame_is_whole(frame, devices, fail_at):
+    """tdt_multi.hip: a dispatch that fails at device i after devices < i were launched drains them, resets the frame state
+    (no stale ev_gathered wait, no timing of a frame that never assembled) and the next dispatch renders the whole frame."""
+    scene, cam, img = frame
+    r = rt.Renderer(scene, cam, devices=devices)
+    try:
+        assert (r.render().view(np.uint32) == img.view(np.uint32)).all()
+        r.ctx.multi_fail(fail_at)
+        with pytest.raises(rt.TdtError) as e:
+            r.dispatch()
+        assert e.value.code == rt.ERR_INVALID_OPERATION and "injected" in str(e.value)
+        with pytest.raises(rt.TdtError):                     # no frame to time
+            r.ctx.multi_timing()
+        for _ in range(2):
+            assert (r.render().view(np.uint32) == img.view(np.uint32)).all()
+        assert len(r.ctx.multi_timing()[0]) == len(devices)
+        assert r.ctx.multi_rccl_ranks() == 0                 # shares of one GPU: peer copies, no communicator
+    finally:
+        r.close()
+
+
+def test_rccl_ranks_of_a_one_device_communicator(frame):
+    scene, cam, img = frame
+    r = rt.Renderer(scene, cam, devices=[0])
+    try:
+        assert (r.render().view(np.uint32) == img.view(np.uint32)).all()
+        assert r.ctx.multi_transport() == "rccl" and r.ctx.multi_rccl_ranks() == 1
+    finally:
+        r.close()
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0, 0]])
+@pytest.mark.parametrize("use_carry", [True, False])
+def test_progressive_passes_on_a_multi_device_context(frame, devices, use_carry):
+    """BASELINE configs[4]'s shape on a node: passes accumulate per device (running sums in the tile buffers, hit-record carry
+    beside them), one resolve + gather + assemble at the end: the bits of the one-pass frame when the records are carried."""
+    import torch
+    scene, cam, img = frame
+    dw, dh = cam.image_width + 1, cam.image_height + 1
+    spp = cam.samples_per_pixel
+    r = rt.Renderer(scene, cam, devices=devices)
+    single = rt.Renderer(scene, cam)
+    acc = torch.zeros((cam.image_height, cam.image_width, 4), dtype=torch.float32, device="cuda:0")
+    carry = torch.zeros((cam.image_height, cam.image_width, 16), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    try:
+        for rep in range(2):                                 # (the second round starts over on the buffers of the first)
+            for b, n in ((0, 5), (5, 3), (8, spp - 8)):
+                r.shader.dispatch_accumulate(dw, dh, 1, b, n, 1 if use_carry else None)
+            r.shader.dispatch_resolve(dw, dh, 1, spp)
+            got = r.texture.read()
+            if use_carry:
+                assert (got.view(np.uint32) == img.view(np.uint32)).all()
+            else:                                            # without carry: the single-device path without carry is the definition
+                t = rt.Texture.wrap_device(single.ctx, acc.data_ptr(), cam.image_width, cam.image_height)
+                for b, n in ((0, 5), (5, 3), (8, spp - 8)):
+                    single.shader.dispatch_accumulate(dw, dh, 1, b, n, None)
+                single.shader.dispatch_resolve(dw, dh, 1, spp)
+                assert (got.view(np.uint32) == t.read().view(np.uint32)).all()
+        assert (r.render().view(np.uint32) == img.view(np.uint32)).all()      # and an ordinary frame afterwards
+    finally:
+        r.close(); single.close()

@@ -1,0 +1,33 @@
+"""Spill / occupancy guard (CPU: hipcc cross-compiles): the trace kernels sit a few registers under the 128-VGPR cap their
+1024-thread blocks impose; the next feature must fail HERE, not silently run 15 % slower."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def rows():
+    import kernel_resources
+    return kernel_resources.collect()
+
+
+def test_product_trace_kernels_do_not_spill_and_keep_four_waves(rows):
+    product = [r for r in rows if r["name"].startswith("tdt::trace_kernel<false")]
+    assert len(product) >= 50                     # every row of kTraceVariants + the two general kernels
+    for r in product:
+        assert r["ScratchSize [bytes/lane]"] == 0, r
+        assert r["VGPRs Spill"] == 0, r
+        assert r["Occupancy [waves/SIMD]"] >= 4, r
+        assert r["VGPRs"] <= 128, r
+        assert r["LDS Size [bytes/block]"] <= 160 * 1024, r
+
+
+def test_every_kernel_fits_the_cu(rows):
+    for r in rows:
+        assert r["LDS Size [bytes/block]"] <= 160 * 1024, r
+        if not r["name"].startswith("tdt::trace_kernel<true"):     # (the instrumented builds may spill: they are never timed)
+            assert r["ScratchSize [bytes/lane]"] == 0, r

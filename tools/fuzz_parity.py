@@ -14,6 +14,21 @@ import oracle_py
 
 
 
+def with_cell_count(scene, cc):
+    """The same tree under another cell_count uniform: Octree::init_global_buffers' floats[6] = 1.0 / cell_count as f32
+    (octree.rs:49), ints[2] = cell_count."""
+    blobs = {k: v.copy() for k, v in scene.blobs.items()}
+    blobs[6][6] = np.float32(1.0) / np.float32(cc)
+    blobs[7][2] = cc
+    return host.Scene(blobs, scene.counts, scene.name + f"_cc{cc}")
+
+
+def with_zero_tail(scene, nodes):
+    blobs = {k: v.copy() for k, v in scene.blobs.items()}
+    blobs[0] = np.concatenate([blobs[0], np.zeros(2 * nodes, np.uint32)])
+    return host.Scene(blobs, scene.counts, scene.name + f"_tail{nodes}")
+
+
 def run(budget=120.0, seed=1, log=print):
     """Sweep for `budget` seconds; returns (cases, mismatches)."""
     rng = np.random.default_rng(seed)
@@ -26,6 +41,11 @@ def run(budget=120.0, seed=1, log=print):
             scene = host.Scene.generate(kind, depth, 1 << cells_log, max_iter, int(rng.integers(1, 1 << 30)))
         except RuntimeError:
             continue                                                   # scene needs more cells than cell_count
+        flavour = int(rng.integers(0, 4))
+        if flavour == 1:                                               # a cell_count that is not a power of two (the reference's own is 100000)
+            scene = with_cell_count(scene, int(rng.choice([100000, 99999, 12345, 65537, 3000, 1000003])) if rng.random() < 0.7 else int(rng.integers(scene.counts["cells"] + 1, 1 << 21)))
+        if flavour == 2 or (flavour == 1 and rng.random() < 0.5):      # a pre-allocated cells buffer: a tail of zero nodes (main.rs:339-341)
+            scene = with_zero_tail(scene, int(rng.integers(1, 60000)))
         W = int(rng.choice([32, 64, 96, 100, 131])); H = int(rng.choice([32, 64, 70, 97]))
         spp = int(rng.choice([1, 2, 5, 16, 33])); bounce = int(rng.choice([1, 3, 8]))
         mode = int(rng.integers(0, 4))
@@ -47,7 +67,7 @@ def run(budget=120.0, seed=1, log=print):
                 got = r.render()
                 if not (got.view(np.uint32) == ref.view(np.uint32)).all():
                     bad += 1
-                    log(f"MISMATCH kind {kind} depth {depth} cells 2^{cells_log} iter {max_iter} {W}x{H} spp {spp} bounce {bounce} cam mode {mode} frame {k}: "
+                    log(f"MISMATCH {scene.name} kind {kind} depth {depth} cells 2^{cells_log} iter {max_iter} {W}x{H} spp {spp} bounce {bounce} cam mode {mode} frame {k}: "
                           f"{int((got.view(np.uint32) != ref.view(np.uint32)).any(axis=2).sum())} px")
         finally:
             r.close()
