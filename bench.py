@@ -202,7 +202,7 @@ def single_process_leg(args):
     # the job of tests/test_gpu_multi.py; here: the whole covered image was written
     img = r.texture.read()
     written = int((img[..., 3] == 1).sum())
-    out = {"devices": devices, "transport": r.ctx.multi_transport(), "workload": desc, "image": [W, H], "spp": spp,
+    out = {"devices": devices, "transport": r.ctx.multi_transport(), "rccl_ranks": r.ctx.multi_rccl_ranks(), "workload": desc, "image": [W, H], "spp": spp,
            "written_pixels": written, "covered_pixels": px, "steps": args.strong_steps, "ms_per_frame": round(dt * 1e3, 3),
            "value": round(px * spp / dt / 1e6, 2), "unit": "Mray-samples/s",
            "trace_ms_per_device": [round(float(np.mean([row[0][i] for row in rows])), 3) for i in range(n)],

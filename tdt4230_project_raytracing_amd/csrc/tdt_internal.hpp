@@ -50,13 +50,14 @@ struct tdt_ctx {
   tdt_buffer *atomic0;
   tdt_image *image0;
   unsigned long long *counters;
-  unsigned int *queue;          // pixel-queue head
+  unsigned int *queue; unsigned queue_parity, order_parity;   // two pixel-queue heads / two sets of sort counters, used alternately (each launch zeroes the other)
   uint16_t *packed;             // LDS-table image of the bound cells buffer
   const tdt_buffer *packed_of;  // which buffer/version `packed` was built from
   unsigned long long packed_version;
   uint32_t *slot_cost, *slot_acc, *slot_order, *order_hist;   // per queue slot: cost feedback of the last trace dispatch, the hand-out order derived from it; 2 x 256 sort counters
   uint32_t cost_dispatches;            // dispatches summed into slot_cost so far
   uint32_t acc_samples, last_launch_samples;   // samples per pixel behind slot_acc / traced by the last launch
+  int two_phase_min_spp;               // TDT_TWO_PHASE_MIN_SPP: frames with fewer samples per pixel take one pass (16)
   int probe_div;                       // TDT_PROBE_DIV: probe samples of a two-phase frame = spp / probe_div (16)
   float order_blend;                   // TDT_ORDER_BLEND: weight of the 8x8-tile mean in a thin (probe) cost estimate
   uint32_t tile_capacity, cost_tiles;  // allocation size (work-groups); number of work-groups slot_cost holds the last dispatch's costs for (0: none)
@@ -69,6 +70,7 @@ struct tdt_ctx {
   bool force_generic;   // TDT_FORCE_GENERIC=1: always run the literal-arithmetic kernel (A/B testing)
   int event_threshold;  // TDT_EVENT_THRESHOLD=n fixes the event threshold (experiments); 0 = adaptive
   int force_smooth; bool no_cost_accum; float max_share;   // TDT_ORDER_SMOOTH / TDT_NO_COST_ACCUM / TDT_MAX_SHARE (diagnostics)
+  int event_clamp;      // TDT_EVENT_CLAMP: upper clamp of the adaptive event threshold
   float event_k;        // TDT_EVENT_K overrides the adaptive threshold's r (0: chosen from the tree size)
   void *frame_carry; size_t frame_carry_bytes;   // hit-record carry between the two phases of a frame (tdt_dispatch_compute)
   bool no_two_phase;                             // TDT_NO_TWO_PHASE=1

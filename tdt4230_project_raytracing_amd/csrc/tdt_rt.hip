@@ -114,6 +114,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   ns.cells = __builtin_amdgcn_make_buffer_rsrc((void *)P.cells, 0, (int)((P.cells_dwords >> 1) << 3), 0x00020000);
   const MatSource ms = material_source(P);
   const uint32_t total_slots = (uint32_t)P.owned_tiles * 1024u;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && P.queue_next) *P.queue_next = 0u;     // the NEXT launch's queue head (two heads alternate: no memset per launch)
 
   const float inf = __builtin_inff();
   unsigned long long pixel_rt0 = 0ull; bool wave_drained = false; uint32_t lane_S = 0, lane_E = 0, pass_no = 0, pixel_pass0 = 0, evpass_no = 0, pixel_evpass0 = 0;
@@ -377,8 +378,10 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       if (w_rays > kEventWindow) { w_steps >>= 1; w_rays >>= 1; }   // sliding window: the mix of pixels a wave sees changes over a frame
       // (a schedule, not arithmetic of the image: the raw hardware rcp / sqrt do, 3 instructions instead of ~35)
       const float est = 64.0f * __builtin_amdgcn_rcpf(0.5f + __builtin_amdgcn_sqrtf(P.event_k * (float)w_steps * __builtin_amdgcn_rcpf((float)w_rays + 1.0f)));
-      const int th = (int)est;
-      threshold = w_rays < 256u ? 24 : (th < 2 ? 2 : (th > 40 ? 40 : th));
+      // (the upper clamp in the float domain: an integer min against a kernel argument moves the whole threshold update to the
+      // scalar unit through v_readfirstlane, and that VALU -> SALU hand-over stalls every pass: measured 2 %)
+      const int th = (int)__builtin_fminf(est, P.event_clamp);
+      threshold = w_rays < 256u ? 24 : (th < 2 ? 2 : th);
     }
     TDT_TICK(5);
     if (state == ST_NEWRAY) {                         // while-condition rc:271 + OctreeHit prologue rc:399-408
@@ -856,7 +859,10 @@ __global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restric
 // three bench frames, batches win or tie on all of them (1080p/64^3, f = 0.3: 24.8 -> 20.9 ms history-free; 1080p/512^3:
 // 158 -> 155 ms history-free, 125.7 -> 126.9 replay), and no frame in the repository reaches f = 1.
 __global__ __launch_bounds__(512) void order_plan_kernel(const uint32_t *__restrict__ hist, uint32_t g, uint32_t lanes, float max_share,
-                                                         uint32_t *__restrict__ plan) {
+                                                         uint32_t *__restrict__ plan, int smooth, uint32_t *__restrict__ next_set) {
+  // the counters of the NEXT order pass (it alternates between two sets): zeroed here, one launch instead of a memset per frame
+  next_set[threadIdx.x] = 0u; next_set[512 + threadIdx.x] = 0u;
+  if (smooth) { if (threadIdx.x == 0) plan[0] = 0u; return; }       // tile-sum order: always batches
   __shared__ float s_sum[512];
   __shared__ uint32_t s_cnt[512];
   const uint32_t bins = 32u << g, k = threadIdx.x;
@@ -868,13 +874,20 @@ __global__ __launch_bounds__(512) void order_plan_kernel(const uint32_t *__restr
   }
   s_sum[k] = rep * (float)cnt; s_cnt[k] = cnt;
   __syncthreads();
-  if (k == 0) {
-    float total = 0.f; uint32_t n = 0;
-    for (uint32_t b = 0; b < bins; b++) { total += s_sum[b]; n += s_cnt[b]; }
-    uint32_t acc = 0, hi_bin = 0;
-    const uint32_t want = n / 1000u + 1u;
-    for (uint32_t b = 0; b < bins; b++) { acc += s_cnt[b]; if (acc >= want) { hi_bin = b; break; } }
-    const uint32_t idx = (bins - 1u) - hi_bin, e = idx >> g, frac = idx & ((1u << g) - 1u);
+  // inclusive prefix sums over the bins (counts) and the total cost, 9 doubling steps
+  for (uint32_t o = 1; o < 512u; o <<= 1) {
+    const uint32_t c = k >= o ? s_cnt[k - o] : 0u;
+    const float t = k >= o ? s_sum[k - o] : 0.f;
+    __syncthreads();
+    s_cnt[k] += c; s_sum[k] += t;
+    __syncthreads();
+  }
+  const uint32_t n = s_cnt[511];
+  const float total = s_sum[511];
+  const uint32_t want = n / 1000u + 1u;
+  // the first bin (in descending cost order) at which the running count reaches the 99.9th percentile
+  if (s_cnt[k] >= want && (k == 0u || s_cnt[k - 1u] < want)) {
+    const uint32_t idx = (bins - 1u) - k, e = idx >> g, frac = idx & ((1u << g) - 1u);
     const float c_hi = __builtin_ldexpf(1.0f + (float)frac / (float)(1u << g), (int)e);
     plan[0] = (total > 0.f && c_hi * (float)lanes > max_share * total) ? 1u : 0u;
   }
@@ -1052,6 +1065,7 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
                    "bound image is neither camera.image_width x image_height nor a 32 x 32*tiles tile buffer");
   P.spp_begin = spp_begin; P.spp_count = spp_count; P.mode = mode; P.total_spp = total_spp;
   P.event_threshold = ctx->event_threshold;   // 0: adaptive (see trace_kernel)
+  P.event_clamp = (float)ctx->event_clamp;
   {  // r of the adaptive event threshold (see trace_kernel): 0.10 up to 1.4 MiB of cells, 0.35 from 5 MiB on (refitted twice in round 2:
      // the traversal step lost a fifth of its instructions, which moves the optimum towards fewer, fuller event passes)
     const float mib = (float)ctx->ssbo[TDT_SLOT_CELLS]->bytes / 1048576.0f;
@@ -1081,7 +1095,7 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     // LDS-table image of the bound cells buffer (rebuilt only when the buffer or its contents changed)
     const tdt_buffer *cb = ctx->ssbo[TDT_SLOT_CELLS];
     if (!ctx->packed) TDT_HIP(ctx, hipMalloc((void **)&ctx->packed, (size_t)tdt::kLdsCells * 8 * sizeof(uint16_t)));
-    if (!ctx->queue) TDT_HIP(ctx, hipMalloc((void **)&ctx->queue, sizeof(unsigned int)));
+    if (!ctx->queue) { TDT_HIP(ctx, hipMalloc((void **)&ctx->queue, 2 * sizeof(unsigned int))); TDT_HIP(ctx, hipMemsetAsync(ctx->queue, 0, 2 * sizeof(unsigned int), ctx->stream)); ctx->queue_parity = 0; }
     P.lds_nodes = buf_nodes < tdt::kLdsCells * 8u ? (buf_nodes & ~7u) : tdt::kLdsCells * 8u;
     if (ctx->packed_of != cb || ctx->packed_version != cb->version) {
       if (!ctx->scan) TDT_HIP(ctx, hipMalloc((void **)&ctx->scan, 4 * sizeof(uint32_t)));
@@ -1100,7 +1114,7 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
       ctx->max_parent_value = res[0]; ctx->max_any_value = res[1]; ctx->live_nodes = res[2];
       ctx->packed_of = cb; ctx->packed_version = cb->version;
     }
-    P.packed = ctx->packed; P.queue = ctx->queue;
+    P.packed = ctx->packed; P.queue = ctx->queue + ctx->queue_parity; P.queue_next = ctx->queue + (ctx->queue_parity ^ 1u);      // (the parity flips once the launch is in the stream)
     // cost-feedback hand-out order (see order_scatter_kernel); TDT_NO_COST_ORDER=1: image order
     if (!ctx->no_cost_order) {
       if (ctx->tile_capacity < (uint32_t)t.owned) {
@@ -1111,7 +1125,7 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
         TDT_HIP(ctx, hipMalloc((void **)&ctx->slot_cost, (size_t)t.owned * 1024 * sizeof(uint32_t)));
         TDT_HIP(ctx, hipMalloc((void **)&ctx->slot_order, (size_t)t.owned * 1024 * sizeof(uint32_t)));
         TDT_HIP(ctx, hipMalloc((void **)&ctx->slot_acc, (size_t)t.owned * 1024 * sizeof(uint32_t)));
-        if (!ctx->order_hist) TDT_HIP(ctx, hipMalloc((void **)&ctx->order_hist, 1028 * sizeof(uint32_t)));
+        if (!ctx->order_hist) { TDT_HIP(ctx, hipMalloc((void **)&ctx->order_hist, (2048 + 4) * sizeof(uint32_t))); TDT_HIP(ctx, hipMemsetAsync(ctx->order_hist, 0, (2048 + 4) * sizeof(uint32_t), ctx->stream)); ctx->order_parity = 0; }
         ctx->tile_capacity = (uint32_t)t.owned;
       }
       // what this dispatch traces: if it equals what the recorded costs were measured on (a still camera: progressive
@@ -1135,18 +1149,19 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
         if (smooth) ctx->acc_samples = 0;               // (tile-sum mode drops the sums after use: order_scatter_kernel)
         const uint32_t n_slots = (uint32_t)t.owned * 1024u, n_chunks = (n_slots + tdt::kOrderChunk - 1) / tdt::kOrderChunk;
         const uint32_t og = tdt::kOrderBits;
-        TDT_HIP(ctx, hipMemsetAsync(ctx->order_hist, 0, 1024 * sizeof(uint32_t), ctx->stream));
-        hipLaunchKernelGGL(tdt::order_hist_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, ctx->slot_acc, n_slots, ctx->order_hist, og, smooth, keep_costs ? 1 : 0, blend);
+        // two sets of sort counters alternate: the plan kernel of this pass zeroes the set of the next one
+        uint32_t *hist = ctx->order_hist + 1024u * ctx->order_parity, *hist_next = ctx->order_hist + 1024u * (ctx->order_parity ^ 1u), *plan = ctx->order_hist + 2048;
+        hipLaunchKernelGGL(tdt::order_hist_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, ctx->slot_acc, n_slots, hist, og, smooth, keep_costs ? 1 : 0, blend);
         {
           const float max_share = ctx->max_share;
           const uint32_t lanes = (uint32_t)ctx->num_cus * TDT_BLOCKS_PER_CU * TDT_BLOCK;
-          if (!smooth) hipLaunchKernelGGL(tdt::order_plan_kernel, dim3(1), dim3(512), 0, ctx->stream, ctx->order_hist, og, lanes, max_share, ctx->order_hist + 1024);
-          else TDT_HIP(ctx, hipMemsetAsync(ctx->order_hist + 1024, 0, sizeof(uint32_t), ctx->stream));
-          P.plan = ctx->order_hist + 1024;
+          hipLaunchKernelGGL(tdt::order_plan_kernel, dim3(1), dim3(512), 0, ctx->stream, hist, og, lanes, max_share, plan, smooth, hist_next);
+          P.plan = plan;
         }
         hipLaunchKernelGGL(tdt::order_scatter_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, ctx->slot_acc, n_slots,
-                           ctx->order_hist, ctx->order_hist + 512, ctx->slot_order, og, smooth, blend);
+                           hist, hist + 512, ctx->slot_order, og, smooth, blend);
         TDT_HIP(ctx, hipGetLastError());
+        ctx->order_parity ^= 1u;                        // (only now: a failed launch leaves the zeroed set in place)
         P.slot_order = ctx->slot_order;
       } else {                                        // no usable history: image order, fresh cost array
         TDT_HIP(ctx, hipMemsetAsync(ctx->slot_cost, 0, (size_t)t.owned * 1024 * sizeof(uint32_t), ctx->stream));
@@ -1157,7 +1172,6 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
       ctx->cost_sig = sig;
       ctx->cost_tiles = (uint32_t)t.owned;            // the kernel launched below records this dispatch's costs
     }
-    TDT_HIP(ctx, hipMemsetAsync(ctx->queue, 0, sizeof(unsigned int), ctx->stream));
   }
   if (t.owned > 0) {
     // trace: one persistent block per CU (fewer when there is less work than lanes); resolve: a thread per pixel
@@ -1177,9 +1191,12 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     // resident: every node that is not all zeros sits in the LDS table (a pre-allocated buffer's tail of zero nodes reads as the
     // table's all-EMPTY sentinel cell does, and as nodes past the end of the buffer do) and fits its 16-bit entries
     const bool resident = buf_nodes > 0 && ctx->live_nodes <= P.lds_nodes && ctx->max_any_value <= tdt::kPackedMaxValue;
+    // ... and then only the live cells are staged: the reference's demo scene is 19 cells in a buffer of 6259 (every block would copy
+    // 82 KB of zeros at launch), and whatever lies past them reads as the sentinel cell
+    if (resident && !ctx->no_specialise) P.lds_nodes = (ctx->live_nodes + 7u) & ~7u;
     // FORM_TABLE: thresholds for every cell of the LDS table, built once per (cell_count, inv_cell_count, cells)
     bool table_form = false;
-    if (mode != 2 && !counts_out && !pow2 && !ctx->force_generic && !ctx->no_specialise && !ctx->no_table_form && depth_ok && P.cell_count > 0 && resident) {
+    if (mode != 2 && !counts_out && !pow2 && !ctx->force_generic && !ctx->no_specialise && !ctx->no_table_form && depth_ok && P.cell_count > 0 && resident && P.lds_nodes > 0) {
       const uint32_t n_thr = (P.lds_nodes + 7u) >> 3;
       uint32_t ic_bits; std::memcpy(&ic_bits, &P.inv_cell_count, 4);
       if (ctx->thr_cc != P.cell_count || ctx->thr_ic_bits != ic_bits || ctx->thr_n != n_thr || !ctx->thr) {
@@ -1281,6 +1298,7 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     else hipLaunchKernelGGL(tdt::resolve_kernel, grid4, block4, 0, ctx->stream, P);
 #undef TDT_LAUNCH
     TDT_HIP(ctx, hipGetLastError());
+    if (mode != 2) ctx->queue_parity ^= 1u;           // this launch zeroes the other head; a launch that failed leaves this one at zero
   }
   if (counts_out) {
     TDT_HIP(ctx, hipMemcpyAsync(counts_out, ctx->counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
@@ -1336,6 +1354,7 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
     ctx->no_bricks = getenv("TDT_NO_BRICKS") != nullptr;
     const char *ms = getenv("TDT_MAX_SHARE"); ctx->max_share = ms ? (float)atof(ms) : 1.0f;
     const char *ob = getenv("TDT_ORDER_BLEND"); ctx->order_blend = ob ? (float)atof(ob) : 0.5f;
+    const char *tp = getenv("TDT_TWO_PHASE_MIN_SPP"); ctx->two_phase_min_spp = tp && atoi(tp) >= 2 ? atoi(tp) : 16;
     const char *pd = getenv("TDT_PROBE_DIV"); ctx->probe_div = pd && atoi(pd) >= 2 && atoi(pd) <= 64 ? atoi(pd) : 16; }
   ctx->scan = nullptr; ctx->max_parent_value = ctx->max_any_value = ctx->live_nodes = 0xFFFFFFFFu;
   ctx->thr = nullptr; ctx->thr_cc = 0; ctx->thr_ic_bits = 0; ctx->thr_n = 0; ctx->thr_ok = false;
@@ -1343,7 +1362,8 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
   { const char *fg = getenv("TDT_FORCE_GENERIC"); ctx->force_generic = fg && fg[0] == '1';
     const char *ns_ = getenv("TDT_NO_SPECIALISE"); ctx->no_specialise = ns_ && ns_[0] == '1';
     const char *et = getenv("TDT_EVENT_THRESHOLD"); ctx->event_threshold = et ? atoi(et) : 0;
-    const char *ek = getenv("TDT_EVENT_K"); ctx->event_k = ek ? (float)atof(ek) : 0.0f; }
+    const char *ek = getenv("TDT_EVENT_K"); ctx->event_k = ek ? (float)atof(ek) : 0.0f;
+    const char *ec = getenv("TDT_EVENT_CLAMP"); ctx->event_clamp = ec && atoi(ec) >= 2 && atoi(ec) <= 64 ? atoi(ec) : 40; }
   if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
   else {
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -1665,7 +1685,7 @@ int tdt_dispatch_compute(tdt_compute *c, int width, int height, int depth) {
   // same bits as one pass (tests/test_gpu_fullsize.py).  Frames that repeat their inputs take one pass in the exact order.
   tdt_ctx *ctx = c->ctx;
   const int spp = c->samples_per_pixel;
-  bool ready = ctx->image0 != nullptr && !ctx->no_cost_order && !ctx->no_two_phase && spp >= 16 && spp / ctx->probe_div >= 1;
+  bool ready = ctx->image0 != nullptr && !ctx->no_cost_order && !ctx->no_two_phase && spp >= ctx->two_phase_min_spp && spp >= 2;
   for (int sl : {TDT_SLOT_CELLS, TDT_SLOT_MATERIALS, TDT_SLOT_ALBEDOS, TDT_SLOT_METAL, TDT_SLOT_DIELECTRIC, TDT_SLOT_OCTREE_FLOATS, TDT_SLOT_OCTREE_INTS})
     ready = ready && ctx->ssbo[sl] != nullptr;
   if (ready && ctx->ssbo[TDT_SLOT_OCTREE_FLOATS]->bytes >= 28 && ctx->ssbo[TDT_SLOT_OCTREE_INTS]->bytes >= 12) {
@@ -1684,7 +1704,7 @@ int tdt_dispatch_compute(tdt_compute *c, int width, int height, int depth) {
         TDT_HIP(ctx, hipMalloc(&ctx->frame_carry, need));
         ctx->frame_carry_bytes = need;
       }
-      const int probe = spp / ctx->probe_div;        // spp/16; measured: 1/8 and 1/32 are 0-3 % slower, 1/64 5 % (TDT_PROBE_DIV)
+      const int probe = spp / ctx->probe_div >= 1 ? spp / ctx->probe_div : 1;        // spp/16; measured: 1/8 and 1/32 are 0-3 % slower, 1/64 5 % (TDT_PROBE_DIV)
       ctx->probe_launch = true;
       phase_mark(ctx, 0);
       int rc = launch(c, width, height, depth, 1, 0, probe, ctx->frame_carry, 0, nullptr);

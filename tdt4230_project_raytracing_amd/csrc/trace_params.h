@@ -22,7 +22,8 @@ struct TraceParams {
   float *carry;
   uint32_t *pixel_log;          // TDT_PIXEL_LOG diagnostics (8 u32 per queue slot), or null
   unsigned long long *counters; // instrumented launches only: event totals (see Counters)
-  unsigned int *queue;          // global pixel queue head (zeroed before every launch)
+  unsigned int *queue;          // global pixel queue head (zero at launch)
+  unsigned int *queue_next;     // the next launch's head: zeroed by this launch (two heads alternate), or null
   const uint32_t *slot_order;   // queue slots (work-group * 1024 + pixel), most expensive first (from the previous dispatch), or null
   uint32_t *slot_cost;          // per queue slot: pixel time of THIS dispatch (feeds the next one), or null
   const uint16_t *packed;       // cells [0, lds_cells) re-encoded as 16 bits per node: value << 2 | code
@@ -44,5 +45,6 @@ struct TraceParams {
   int32_t mode;                // 0 render (sum, sqrt, clamp, store), 1 accumulate into image, 2 resolve
   int32_t total_spp;           // resolve divisor
   int32_t event_threshold;     // > 0: fixed number of lanes that must wait for the event code; 0: adaptive
+  float event_clamp;           // upper clamp of the adaptive threshold
   float event_k;               // adaptive threshold: r = C_t / (2 C_e) of the model in trace_kernel
 };

@@ -100,7 +100,12 @@ def lib():
             pass
         L = ctypes.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
-            f = getattr(L, name)
+            try:
+                f = getattr(L, name)
+            except AttributeError:
+                if os.environ.get("TDT_LIB"):                # an older build loaded for an A/B run: newer entry points are absent
+                    continue
+                raise
             f.restype = res
             f.argtypes = args
         _lib = L
