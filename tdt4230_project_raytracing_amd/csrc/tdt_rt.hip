@@ -68,6 +68,20 @@ TDT_DEV uint32_t wave_sum(uint32_t v) {
 // of operations for its own pixel, in the same order (bit-identical sums).
 enum : int { ST_DONE = -1, ST_TRAVERSE = 0, ST_HIT = 1, ST_END = 2, ST_FETCH = 3, ST_PRIMARY = 4, ST_NEWRAY = 5 };   // events are the positive states
 
+template <bool AS_MASKS> struct HitOwed;             // (see its use in trace_kernel)
+template <> struct HitOwed<true> {
+  bool use_leaf = false, leaf_rec = false;
+  TDT_DEV void set(bool later_step, bool cube_ok) { use_leaf = later_step; leaf_rec = later_step && cube_ok; }
+  TDT_DEV bool leaf_site() const { return use_leaf; }
+  TDT_DEV bool new_record() const { return leaf_rec; }
+};
+template <> struct HitOwed<false> {
+  uint32_t bits = 0u;
+  TDT_DEV void set(bool later_step, bool cube_ok) { bits = later_step ? (cube_ok ? 3u : 1u) : 0u; }
+  TDT_DEV bool leaf_site() const { return (bits & 1u) != 0u; }
+  TDT_DEV bool new_record() const { return (bits & 2u) != 0u; }
+};
+
 // P.accumulate == 0: the whole of main() rc:234-252; 1: only the sample loop, adding to running sums (a uniform run-time
 // flag, looked at once per pixel, so the scene-specialised variants serve progressive passes too).
 // COUNT: instrumented build that also totals the events defining the algorithmic bytes.
@@ -138,7 +152,13 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   float sr = 0.f, sg = 0.f, sb = 0.f;                // color rc:237
   float t_stride = 0.f, t_octree_max = 0.f, inv_pow_depth = 0.5f;
   int it = 0;                                        // OctreeHit's i rc:410
-  bool use_leaf = false, leaf_rec = false; uint32_t hit_index = 0;
+  // what the hit found by the traversal step still owes the event code: bit 0 = the record is the leaf call site's (it > 0), bit 1 = that
+  // call site writes a new record (its slab test hit).  As two bools the compiler keeps them as lane masks in scalar register pairs and
+  // updates those with a dozen s_and / s_andn2 / s_or per pass; as an integer in a VGPR the pass is 16 scalar instructions shorter — which
+  // is worth 0.8 % where registers are to spare (the whole-depth-table and LDS-resident builds) and costs 0.5-3 % in the brick builds,
+  // which sit at 124-126 of 128 VGPRs: those keep the masks (measured both ways on configs 2 / 3 / 5)
+  HitOwed<BRICK> owed;
+  uint32_t hit_index = 0;
   float leaf_box_x = 0.f, leaf_box_y = 0.f, leaf_box_z = 0.f;
   Carry pc;
   pc.root = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}; pc.leaf = pc.root; pc.root_t = 0.f;
@@ -210,7 +230,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
           // are batched: only a few lanes per step reach a leaf.  The traversal registers are
           // dead from here on, so they carry the cube.
           leaf_box_x = cx; leaf_box_y = cy; leaf_box_z = cz; inv_pow_depth = cs; t_stride = t_enter;
-          use_leaf = it > 0; leaf_rec = it > 0 && cube_ok; hit_index = value;
+          owed.set(it > 0, cube_ok); hit_index = value;
           state = ST_HIT;
         } else {
           t_stride = cube_ok ? t_exit : t_octree_max;
@@ -242,9 +262,9 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     if (state == ST_HIT) {                            // RayColor loop body rc:272-295
       if (COUNT) { cnt.scatter_slots += slot64(); cnt.scatter_active++; }
       const MatRef mat = material_fetch(ms, hit_index);
-      if (leaf_rec) { cube_hit_record(r, t_stride, leaf_box_x, leaf_box_y, leaf_box_z, inv_pow_depth, pc.leaf); if (COUNT) cnt.leaf_records++; }
+      if (owed.new_record()) { cube_hit_record(r, t_stride, leaf_box_x, leaf_box_y, leaf_box_z, inv_pow_depth, pc.leaf); if (COUNT) cnt.leaf_records++; }
       loop_count += 1;
-      const HitTmp &src = use_leaf ? pc.leaf : pc.root;
+      const HitTmp &src = owed.leaf_site() ? pc.leaf : pc.root;
       Hit h;
       h.px = src.px; h.py = src.py; h.pz = src.pz; h.nx = src.nx; h.ny = src.ny; h.nz = src.nz; h.ff = src.ff;
       h.index = hit_index;
@@ -814,7 +834,7 @@ __global__ __launch_bounds__(1024) void order_hist_kernel(const uint32_t *__rest
   __syncthreads();
   if (threadIdx.x < 512 && s_bin[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_bin[threadIdx.x]);
 }
-__global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restrict__ cost, uint32_t *__restrict__ acc, uint32_t n, const uint32_t *__restrict__ hist,
+__global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restrict__ cost, uint32_t *__restrict__ acc, uint32_t n, const uint32_t *__restrict__ prefix,
                                                              uint32_t *__restrict__ cursor, uint32_t *__restrict__ order, uint32_t g, int smooth, float blend) {
   __shared__ uint32_t s_bin[512], s_base[512];
   if (threadIdx.x < 512) s_bin[threadIdx.x] = 0;
@@ -826,10 +846,8 @@ __global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restric
   }
   __syncthreads();
   if (threadIdx.x < 512) {
-    uint32_t before = 0;
-    for (uint32_t b = 0; b < threadIdx.x; b++) before += hist[b];
     const uint32_t mine = s_bin[threadIdx.x];
-    s_base[threadIdx.x] = before + (mine ? atomicAdd(&cursor[threadIdx.x], mine) : 0u);
+    s_base[threadIdx.x] = prefix[threadIdx.x] + (mine ? atomicAdd(&cursor[threadIdx.x], mine) : 0u);
   }
   __syncthreads();
   for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) {
@@ -859,10 +877,9 @@ __global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restric
 // three bench frames, batches win or tie on all of them (1080p/64^3, f = 0.3: 24.8 -> 20.9 ms history-free; 1080p/512^3:
 // 158 -> 155 ms history-free, 125.7 -> 126.9 replay), and no frame in the repository reaches f = 1.
 __global__ __launch_bounds__(512) void order_plan_kernel(const uint32_t *__restrict__ hist, uint32_t g, uint32_t lanes, float max_share,
-                                                         uint32_t *__restrict__ plan, int smooth, uint32_t *__restrict__ next_set) {
+                                                         uint32_t *__restrict__ plan, int smooth, uint32_t *__restrict__ next_set, uint32_t *__restrict__ prefix) {
   // the counters of the NEXT order pass (it alternates between two sets): zeroed here, one launch instead of a memset per frame
   next_set[threadIdx.x] = 0u; next_set[512 + threadIdx.x] = 0u;
-  if (smooth) { if (threadIdx.x == 0) plan[0] = 0u; return; }       // tile-sum order: always batches
   __shared__ float s_sum[512];
   __shared__ uint32_t s_cnt[512];
   const uint32_t bins = 32u << g, k = threadIdx.x;
@@ -882,6 +899,10 @@ __global__ __launch_bounds__(512) void order_plan_kernel(const uint32_t *__restr
     s_cnt[k] += c; s_sum[k] += t;
     __syncthreads();
   }
+  prefix[k] = s_cnt[k] - cnt;                         // where bin k starts in the output: every block of the scatter reads it instead of summing the bins before k
+  if (k == 0) plan[0] = 0u;                           // batches, unless the test below says otherwise (tile-sum order: always batches)
+  if (smooth) return;
+  __syncthreads();
   const uint32_t n = s_cnt[511];
   const float total = s_sum[511];
   const uint32_t want = n / 1000u + 1u;
@@ -1125,7 +1146,7 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
         TDT_HIP(ctx, hipMalloc((void **)&ctx->slot_cost, (size_t)t.owned * 1024 * sizeof(uint32_t)));
         TDT_HIP(ctx, hipMalloc((void **)&ctx->slot_order, (size_t)t.owned * 1024 * sizeof(uint32_t)));
         TDT_HIP(ctx, hipMalloc((void **)&ctx->slot_acc, (size_t)t.owned * 1024 * sizeof(uint32_t)));
-        if (!ctx->order_hist) { TDT_HIP(ctx, hipMalloc((void **)&ctx->order_hist, (2048 + 4) * sizeof(uint32_t))); TDT_HIP(ctx, hipMemsetAsync(ctx->order_hist, 0, (2048 + 4) * sizeof(uint32_t), ctx->stream)); ctx->order_parity = 0; }
+        if (!ctx->order_hist) { TDT_HIP(ctx, hipMalloc((void **)&ctx->order_hist, (2048 + 4 + 512) * sizeof(uint32_t))); TDT_HIP(ctx, hipMemsetAsync(ctx->order_hist, 0, (2048 + 4 + 512) * sizeof(uint32_t), ctx->stream)); ctx->order_parity = 0; }
         ctx->tile_capacity = (uint32_t)t.owned;
       }
       // what this dispatch traces: if it equals what the recorded costs were measured on (a still camera: progressive
@@ -1155,11 +1176,11 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
         {
           const float max_share = ctx->max_share;
           const uint32_t lanes = (uint32_t)ctx->num_cus * TDT_BLOCKS_PER_CU * TDT_BLOCK;
-          hipLaunchKernelGGL(tdt::order_plan_kernel, dim3(1), dim3(512), 0, ctx->stream, hist, og, lanes, max_share, plan, smooth, hist_next);
+          hipLaunchKernelGGL(tdt::order_plan_kernel, dim3(1), dim3(512), 0, ctx->stream, hist, og, lanes, max_share, plan, smooth, hist_next, plan + 4);
           P.plan = plan;
         }
         hipLaunchKernelGGL(tdt::order_scatter_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, ctx->slot_acc, n_slots,
-                           hist, hist + 512, ctx->slot_order, og, smooth, blend);
+                           plan + 4, hist + 512, ctx->slot_order, og, smooth, blend);
         TDT_HIP(ctx, hipGetLastError());
         ctx->order_parity ^= 1u;                        // (only now: a failed launch leaves the zeroed set in place)
         P.slot_order = ctx->slot_order;
