@@ -62,6 +62,8 @@ struct tdt_ctx {
   float order_blend;                   // TDT_ORDER_BLEND: weight of the 8x8-tile mean in a thin (probe) cost estimate
   uint32_t tile_capacity, cost_tiles;  // allocation size (work-groups); number of work-groups slot_cost holds the last dispatch's costs for (0: none)
   CostSig cost_sig;                    // what those costs were measured on (camera, octree parameters, buffer versions, partition)
+  // miss pre-pass (cameras outside the octree: miss_prepass_kernel): done flag per queue slot, the filtered hand-out order, scratch
+  uint8_t *slot_done; uint32_t *slot_live, *filter_counts; uint32_t done_capacity; bool use_done, no_prepass;   // use_done: set for the launches of a frame whose pre-pass ran (TDT_NO_PREPASS=1: never)
   bool no_cost_order;           // TDT_NO_COST_ORDER=1: always hand work-groups out in image order
   uint32_t *scan;               // device scratch of scan_cells_kernel
   uint32_t max_parent_value, max_any_value, live_nodes;   // its result for `packed_of` (live_nodes: one past the last node that is not all zeros)

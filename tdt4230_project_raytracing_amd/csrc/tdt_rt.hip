@@ -457,6 +457,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const TraceParams P) {
   if (!pixel_of_thread(P, x, y, pix)) return;
   float4 *dst = reinterpret_cast<float4 *>(P.image) + pix;
   float4 a = *dst;
+  if (a.w != 0.f) return;                             // running sums carry alpha 0; a pixel that already holds its colour (alpha 1: the miss pre-pass finished it) is left alone
   const float n = (float)P.total_spp;
   float4 o;
   o.x = f_min(f_max(__builtin_sqrtf(a.x / n), 0.f), 1.f);
@@ -464,6 +465,115 @@ __global__ __launch_bounds__(256) void resolve_kernel(const TraceParams P) {
   o.z = f_min(f_max(__builtin_sqrtf(a.z / n), 0.f), 1.f);
   o.w = 1.0f;
   *dst = o;
+}
+
+// Miss pre-pass (cameras OUTSIDE the octree).  A pixel all of whose primary rays miss the root cube — and whose first traversal
+// position, origin + 6e-5 d, lies outside it too — never enters the tree: every sample runs PRIMARY -> NEWRAY -> one traversal step
+// that leaves at once -> END with the sky colour (rc:297-301), and since no call site ever writes a record, nothing is carried from
+// sample to sample.  For a camera that looks at a model from outside that is most of the image, and in the trace kernel those pixels
+// cost a lane slot, a queue draw and (in a two-phase frame) 64 B of carry each way.  One thread per pixel evaluates exactly the
+// arithmetic those states evaluate — primary ray, reciprocals, root slab test, the in-octree test of the first step, the sky
+// polynomial, the sum in sample order, main()'s sqrt / clamp — and, if EVERY sample misses, stores the pixel's final colour and
+// marks its queue slot done; the first sample that would enter the tree leaves the pixel to the trace kernel, untouched.  The hand-
+// out order of the frame's launches is then filtered (filter_*_kernel), so the trace kernel never sees a finished pixel.  Same bits:
+// tests/test_gpu_prepass.py (outside / grazing / far cameras against the oracle, with and without the pre-pass).
+__global__ __launch_bounds__(256) void miss_prepass_kernel(const TraceParams P, uint8_t *__restrict__ done) {
+  int x, y; size_t pix;
+  const bool covered = pixel_of_thread(P, x, y, pix);
+  const size_t slot = (size_t)(blockIdx.x >> 2) * 1024u + (size_t)((blockIdx.x & 3) * 256 + threadIdx.x);
+  bool all_miss = covered;
+  float sr = 0.f, sg = 0.f, sb = 0.f;
+  const float inf = __builtin_inff();
+  for (int s = 0; s < P.samples_per_pixel && __ballot(all_miss) != 0ull; s++) {
+    const Ray r = primary_ray(P, x, y, s);            // rc:240-245 (PRIMARY)
+    float ix, iy, iz;
+    q_rcp3(r.dx, r.dy, r.dz, ix, iy, iz);             // NEWRAY: OctreeHit's root test rc:399-408
+    const float lx = (P.min_x + -r.ox) * ix, ly = (P.min_y + -r.oy) * iy, lz = (P.min_z + -r.oz) * iz;
+    const float ux = ((P.min_x + P.scale) + -r.ox) * ix, uy = ((P.min_y + P.scale) + -r.oy) * iy, uz = ((P.min_z + P.scale) + -r.oz) * iz;
+    const float mnx = hw_min(lx, ux), mny = hw_min(ly, uy), mnz = hw_min(lz, uz);
+    const float mxx = hw_max(lx, ux), mxy = hw_max(ly, uy), mxz = hw_max(lz, uz);
+    const float t_enter = hw_max(hw_max(hw_max(mnx, 0.0003f), mny), mnz);
+    const float t_exit = hw_min(hw_min(hw_min(mxx, inf), mxy), mxz);
+    const bool root_hit = t_exit >= t_enter;
+    // the first traversal step of a ray whose root test missed: t_stride = the root call site's t, still 0 for this pixel;
+    // inv_pow_depth = 0.5 (rc:412); it leaves through the in-octree test rc:417 (written as the literal form of the test)
+    const float adv = f_max(0.0001f * (0.5f + 0.1f), 0.000001f);
+    const float tt = 0.f + adv;
+    const float wx = tt * r.dx + r.ox, wy = tt * r.dy + r.oy, wz = tt * r.dz + r.oz;
+    const float px = (wx + -P.min_x) * P.inv_scale, py = (wy + -P.min_y) * P.inv_scale, pz = (wz + -P.min_z) * P.inv_scale;
+    const float ex = f_fract(px) + -px, ey = f_fract(py) + -py, ez = f_fract(pz) + -pz;
+    const bool in_box = !((__builtin_fabsf(ez) + __builtin_fabsf(ey)) != -__builtin_fabsf(ex));
+    const bool steps_in = (0 < P.max_iter) && (0.f < inf) && in_box;
+    if (root_hit || steps_in) all_miss = false;
+    const float yp = r.dy + 1.0f;                     // END with loop_count == 0: the sky rc:299-301
+    const float w = 1.0f + -(0.5f * yp);
+    sr = sr + (w + 0.25f * yp); sg = sg + (w + 0.35f * yp); sb = sb + 1.0f;
+  }
+  if (covered && all_miss) {                          // main() rc:249-251
+    const float n = (float)P.samples_per_pixel;
+    float4 o;
+    o.x = f_min(f_max(__builtin_sqrtf(sr / n), 0.f), 1.f);
+    o.y = f_min(f_max(__builtin_sqrtf(sg / n), 0.f), 1.f);
+    o.z = f_min(f_max(__builtin_sqrtf(sb / n), 0.f), 1.f);
+    o.w = 1.0f;
+    *(reinterpret_cast<float4 *>(P.image) + pix) = o;
+  }
+  done[slot] = (!covered || all_miss) ? 1u : 0u;      // (slots outside the covered image have nothing to trace either)
+}
+
+// The hand-out order without the slots the pre-pass finished: a stable compaction in two passes over chunks of kFilterChunk entries
+// (per-chunk counts; then every block sums the counts before its chunk and writes).  order == nullptr: image order (the identity).
+constexpr uint32_t kFilterChunk = 4096;
+TDT_DEV uint32_t filter_rank(bool live, uint32_t *s_wave, uint32_t &block_total) {      // this thread's rank among the live entries of its round
+  const unsigned long long m = __ballot(live);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+  for (uint32_t w = 0; w < 16u; w++) { const uint32_t c = s_wave[w]; before += w < wave ? c : 0u; total += c; }
+  __syncthreads();
+  block_total = total;
+  return before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+__global__ __launch_bounds__(1024) void filter_count_kernel(const uint32_t *__restrict__ order, const uint8_t *__restrict__ done, uint32_t n, uint32_t *__restrict__ counts) {
+  __shared__ uint32_t s_wave[16];
+  uint32_t total = 0;
+  for (uint32_t r = 0; r < kFilterChunk / 1024u; r++) {
+    const uint32_t i = blockIdx.x * kFilterChunk + r * 1024u + threadIdx.x;
+    const bool live = i < n && done[order ? order[i] : i] == 0u;
+    uint32_t t;
+    (void)filter_rank(live, s_wave, t);
+    total += t;
+  }
+  if (threadIdx.x == 0) counts[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(1024) void filter_write_kernel(const uint32_t *__restrict__ order, const uint8_t *__restrict__ done, uint32_t n, const uint32_t *__restrict__ counts,
+                                                            uint32_t *__restrict__ out) {
+  // live entries of the chunks before this one, and of all chunks: where this block writes, and where the padding starts.  The
+  // finished slots' places at the end of the list are filled with 0xFFFFFFFF, which the trace kernel's fetch reads as "the queue is
+  // empty" (the value it hands to lanes beyond the last slot anyway) — so the kernel needs no count and no code of its own for this
+  __shared__ uint32_t s_wave[16], s_sum[2];
+  uint32_t part = 0, all = 0;
+  for (uint32_t c = threadIdx.x; c < gridDim.x; c += 1024u) { const uint32_t v = counts[c]; all += v; part += c < blockIdx.x ? v : 0u; }
+  for (int o = 32; o > 0; o >>= 1) { part += (uint32_t)__shfl_xor((int)part, o, 64); all += (uint32_t)__shfl_xor((int)all, o, 64); }
+  if (threadIdx.x < 2) s_sum[threadIdx.x] = 0u;
+  __syncthreads();
+  if ((threadIdx.x & 63u) == 0) { atomicAdd(&s_sum[0], part); atomicAdd(&s_sum[1], all); }
+  __syncthreads();
+  uint32_t base = s_sum[0];
+  uint32_t pad = s_sum[1] + (blockIdx.x * kFilterChunk - base);      // finished entries of the chunks before this one come first in the padding
+  __syncthreads();
+  for (uint32_t r = 0; r < kFilterChunk / 1024u; r++) {
+    const uint32_t i = blockIdx.x * kFilterChunk + r * 1024u + threadIdx.x;
+    const uint32_t slot = i < n ? (order ? order[i] : i) : 0u;
+    const bool live = i < n && done[slot] == 0u;
+    uint32_t t;
+    const uint32_t rank = filter_rank(live, s_wave, t);
+    if (live) out[base + rank] = slot;
+    else if (i < n) out[pad + (threadIdx.x - rank)] = 0xFFFFFFFFu;      // (entries of one round: valid ones first, so t - rank finished ones precede thread t)
+    const uint32_t first = blockIdx.x * kFilterChunk + r * 1024u, valid = first >= n ? 0u : (n - first < 1024u ? n - first : 1024u);
+    base += t; pad += valid - t;
+  }
 }
 
 // Re-encode the first n nodes of the cells payload as one dword each for the LDS table (NodeSource).
@@ -1112,6 +1222,23 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     }
   }
   const uint32_t buf_nodes = P.cells_dwords >> 1;
+  if (mode == 3) {                                    // the miss pre-pass of a frame (see miss_prepass_kernel): done flags for every queue slot
+    if (t.owned <= 0) return TDT_OK;
+    if (ctx->done_capacity < (uint32_t)t.owned) {
+      if (ctx->slot_done) (void)hipFree(ctx->slot_done);
+      if (ctx->slot_live) (void)hipFree(ctx->slot_live);
+      if (ctx->filter_counts) (void)hipFree(ctx->filter_counts);
+      ctx->slot_done = nullptr; ctx->slot_live = nullptr; ctx->filter_counts = nullptr; ctx->done_capacity = 0;
+      const size_t n = (size_t)t.owned * 1024;
+      TDT_HIP(ctx, hipMalloc((void **)&ctx->slot_done, n));
+      TDT_HIP(ctx, hipMalloc((void **)&ctx->slot_live, n * sizeof(uint32_t)));
+      TDT_HIP(ctx, hipMalloc((void **)&ctx->filter_counts, ((n + tdt::kFilterChunk - 1) / tdt::kFilterChunk + 1) * sizeof(uint32_t)));
+      ctx->done_capacity = (uint32_t)t.owned;
+    }
+    hipLaunchKernelGGL(tdt::miss_prepass_kernel, dim3((unsigned)t.owned * 4u), dim3(256), 0, ctx->stream, P, ctx->slot_done);
+    TDT_HIP(ctx, hipGetLastError());
+    return TDT_OK;
+  }
   if (t.owned > 0 && mode != 2) {
     // LDS-table image of the bound cells buffer (rebuilt only when the buffer or its contents changed)
     const tdt_buffer *cb = ctx->ssbo[TDT_SLOT_CELLS];
@@ -1193,6 +1320,14 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
       ctx->cost_sig = sig;
       ctx->cost_tiles = (uint32_t)t.owned;            // the kernel launched below records this dispatch's costs
     }
+  }
+  if (t.owned > 0 && mode != 2 && ctx->use_done && !counts_out) {
+    // the frame's pre-pass finished some pixels: hand out the others only (the order just built, or image order, minus the done slots)
+    const uint32_t n_slots = (uint32_t)t.owned * 1024u, n_chunks = (n_slots + tdt::kFilterChunk - 1) / tdt::kFilterChunk;
+    hipLaunchKernelGGL(tdt::filter_count_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, P.slot_order, ctx->slot_done, n_slots, ctx->filter_counts);
+    hipLaunchKernelGGL(tdt::filter_write_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, P.slot_order, ctx->slot_done, n_slots, ctx->filter_counts, ctx->slot_live);
+    TDT_HIP(ctx, hipGetLastError());
+    P.slot_order = ctx->slot_live;
   }
   if (t.owned > 0) {
     // trace: one persistent block per CU (fewer when there is less work than lanes); resolve: a thread per pixel
@@ -1370,6 +1505,7 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
     const char *fs = getenv("TDT_ORDER_SMOOTH"); ctx->force_smooth = fs ? atoi(fs) : -1;
     ctx->no_cost_accum = getenv("TDT_NO_COST_ACCUM") != nullptr;
     ctx->no_two_phase = getenv("TDT_NO_TWO_PHASE") != nullptr;
+    ctx->no_prepass = getenv("TDT_NO_PREPASS") != nullptr;
     ctx->no_full = getenv("TDT_NO_FULL_GRID") != nullptr;
     ctx->no_table_form = getenv("TDT_NO_TABLE_FORM") != nullptr;
     ctx->no_bricks = getenv("TDT_NO_BRICKS") != nullptr;
@@ -1414,6 +1550,9 @@ void tdt_ctx_destroy(tdt_ctx *ctx) {
   if (ctx->pixel_log) (void)hipFree(ctx->pixel_log);
   if (ctx->present) (void)hipFree(ctx->present);
   if (ctx->frame_carry) (void)hipFree(ctx->frame_carry);
+  if (ctx->slot_done) (void)hipFree(ctx->slot_done);
+  if (ctx->slot_live) (void)hipFree(ctx->slot_live);
+  if (ctx->filter_counts) (void)hipFree(ctx->filter_counts);
   if (ctx->full_grid) (void)hipFree(ctx->full_grid);
   if (ctx->thr) (void)hipFree(ctx->thr);
   if (ctx->brick_grid) (void)hipFree(ctx->brick_grid);
@@ -1695,10 +1834,34 @@ static void phase_mark(tdt_ctx *ctx, int i) {
   if (hipEventRecord(ctx->phase_ev[i], ctx->stream) == hipSuccess) ctx->phase_n = i + 1;
 }
 
+static int dispatch_frame(tdt_compute *c, int width, int height, int depth);
+
 int tdt_dispatch_compute(tdt_compute *c, int width, int height, int depth) {
   if (!c) return TDT_ERR_INVALID_VALUE;
   if (c->ctx->multi) return tdt::multi_dispatch_compute(c, width, height, depth);
   if (c->kind == TDT_PROGRAM_OCTREE_UPDATE) return tdt::launch_update(c, width, height, depth);
+  tdt_ctx *ctx = c->ctx;
+  // a camera outside the octree: the pixels whose rays all miss it are finished by the miss pre-pass (miss_prepass_kernel) and
+  // taken out of the hand-out order of this frame's launches.  (Inside the octree every ray starts in the root cube: nothing to find.)
+  ctx->use_done = false;
+  const tdt_buffer *of = ctx->ssbo[TDT_SLOT_OCTREE_FLOATS];
+  if (!ctx->no_prepass && of && of->bytes >= 28 && c->samples_per_pixel >= 1 && c->max_bounce >= 1) {
+    float f[7];
+    std::memcpy(f, of->shadow, sizeof f);
+    bool outside = false;
+    for (int a = 0; a < 3; a++) outside = outside || c->origin[a] < f[a] || c->origin[a] > f[a] + f[4];
+    if (outside) {
+      const int rc = launch(c, width, height, depth, 3, 0, 0, nullptr, 0, nullptr);
+      if (rc != TDT_OK) return rc;
+      ctx->use_done = true;
+    }
+  }
+  const int rc = dispatch_frame(c, width, height, depth);
+  ctx->use_done = false;
+  return rc;
+}
+
+static int dispatch_frame(tdt_compute *c, int width, int height, int depth) {
   // A frame whose inputs differ from what the recorded pixel costs were measured on (first frame, moved camera, edited
   // scene) is traced in two phases: spp/16 probe samples per pixel in image (or tile-sum) order, then — the launch below
   // sees identical inputs and fresh costs — the rest in the per-pixel cost order of THIS frame's probe, and a resolve.  Running
