@@ -125,6 +125,13 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   ns.thr = s_thr; ns.thr_f0max = P.thr_f0max;
   ns.full = P.full_grid;
   ns.grid32 = s_grid32; ns.bricks = P.bricks;
+  if (BRICK) {
+    // the bricks' base address in a VGPR pair: as a scalar pair it was the one value the compiler spilled to a VGPR lane and read back
+    // (2 v_readlane + the hazard wait) in EVERY traversal step — the brick builds run out of SGPRs, not of VGPRs
+    uint32_t lo, hi;
+    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(lo), "=v"(hi) : "s"((uint32_t)(uintptr_t)P.bricks), "s"((uint32_t)((uintptr_t)P.bricks >> 32)));
+    ns.bricks = reinterpret_cast<const void *>(((uintptr_t)hi << 32) | (uintptr_t)lo);
+  }
   ns.cells = __builtin_amdgcn_make_buffer_rsrc((void *)P.cells, 0, (int)((P.cells_dwords >> 1) << 3), 0x00020000);
   const MatSource ms = material_source(P);
   const uint32_t total_slots = (uint32_t)P.owned_tiles * 1024u;
