@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc counter_collection.csv files for the trace kernel: the LAST dispatch of the plain (non-probe) trace
+"""Summarise rocprofv3 --pmc counter_collection.csv files for the trace kernel: the LAST dispatch of the product trace
 kernel of each run (tools/pmc_frame.py makes that the frame of interest), its duration, and the derived VALU figures:
 
   issue_util = SQ_INSTS_VALU x 2 cycles (a wave64 instruction on a SIMD32 datapath) / (CUs x 4 SIMDs x clock x duration)
@@ -20,7 +20,7 @@ for d in a.dirs:
             k = r["Kernel_Name"]
             m = re.search(r"trace_kernel<([^>]*)>", k)
             targs = [t.strip() for t in m.group(1).split(",")] if m else []
-            if targs and targs[0] == "false" and not (len(targs) >= 6 and targs[5] == "true"):     # the product build, not the PROBE-named launch
+            if targs and targs[0] == "false":     # the product build (COUNT = false); the LAST such dispatch is the frame's main launch (a probe launch precedes it)
                 acc.setdefault(r["Counter_Name"], []).append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
         for k, v in acc.items():
             last = max(i for i, _, _ in v)
