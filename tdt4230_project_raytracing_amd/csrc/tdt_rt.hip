@@ -99,15 +99,16 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     s_nodes[P.lds_nodes + threadIdx.x] = (uint16_t)((RESIDENT && POW2) ? 0u : kPackedEscape);
   __syncthreads();
   constexpr bool TABLE = FORM == FORM_TABLE;
-  static_assert(!TABLE || (RESIDENT && SAFEV && !BRICK && !FULL), "per-cell thresholds: trees inside the LDS table");
-  __shared__ __attribute__((aligned(8))) float2 s_thr[TABLE ? kLdsCells + 1 : 1];      // FORM_TABLE: x_thresholds of the cells PARENT nodes point at
+  static_assert(!TABLE || (SAFEV && !BRICK && !FULL), "per-cell thresholds: the resident walk, or the jump table's bands of a tree outside the LDS table");
+  constexpr uint32_t kThrCells = !TABLE ? 0u : (RESIDENT ? kLdsCells : kThrTopCells);
+  __shared__ __attribute__((aligned(8))) float2 s_thr[kThrCells + 1];      // FORM_TABLE: x_thresholds of the cells PARENT nodes point at (trees outside the LDS table: of the top cells)
   __shared__ uint32_t s_band;
   if (TABLE) {
-    for (uint32_t i = threadIdx.x; i <= kLdsCells; i += (uint32_t)TDT_BLOCK)
+    for (uint32_t i = threadIdx.x; i <= kThrCells; i += (uint32_t)TDT_BLOCK)
       s_thr[i] = i < P.thr_cells ? reinterpret_cast<const float2 *>(P.thr)[i] : make_float2(2.0f, 2.0f);
     __syncthreads();
   }
-  constexpr int GL = RESIDENT ? 4 : 5;                                 // levels of the top-level jump table (see Grid<GL>)
+  constexpr int GL = top_grid_levels(RESIDENT, TABLE);                 // levels of the top-level jump table (see Grid<GL>)
   constexpr bool kUseGrid = !FULL && !BRICK && !COUNT && POW2 && SAFEV && DEPTH >= GL;   // see build_top_grid (FULL: the whole-depth table in global memory instead; BRICK: the 32-bit table below)
   __shared__ typename Grid<GL>::Entry s_grid[kUseGrid ? Grid<GL>::kEntries : 1];
   __shared__ int s_grid_ok;
@@ -1148,6 +1149,10 @@ const TraceVariant kTraceVariants[] = {
   TDT_V(FORM_TABLE, 3, true, false, false), TDT_V(FORM_TABLE, 4, true, false, false), TDT_V(FORM_TABLE, 5, true, false, false),
   TDT_V(FORM_TABLE, 6, true, false, false), TDT_V(FORM_TABLE, 7, true, false, false), TDT_V(FORM_TABLE, 8, true, false, false),
   TDT_V(FORM_TABLE, 9, true, false, false), TDT_V(FORM_TABLE, 10, true, false, false),
+  // ... and for such a count with the tree outside the LDS table: exact y / z digits, a 4-level jump table with the band its top cells'
+  // thresholds give, node memo; the x index of a walked level by the formula itself
+  TDT_V(FORM_TABLE, 6, false, false, false), TDT_V(FORM_TABLE, 7, false, false, false), TDT_V(FORM_TABLE, 8, false, false, false),
+  TDT_V(FORM_TABLE, 9, false, false, false), TDT_V(FORM_TABLE, 10, false, false, false),
 };
 #undef TDT_V
 #undef TDT_V1
@@ -1357,10 +1362,12 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     // ... and then only the live cells are staged: the reference's demo scene is 19 cells in a buffer of 6259 (every block would copy
     // 82 KB of zeros at launch), and whatever lies past them reads as the sentinel cell
     if (resident && !ctx->no_specialise) P.lds_nodes = (ctx->live_nodes + 7u) & ~7u;
-    // FORM_TABLE: thresholds for every cell of the LDS table, built once per (cell_count, inv_cell_count, cells)
+    // FORM_TABLE: thresholds for every cell of the LDS table (trees outside it: for the top cells, whose decisions the jump table's
+    // band is computed from — their walk evaluates the formula), built once per (cell_count, inv_cell_count, cells)
     bool table_form = false;
-    if (mode != 2 && !counts_out && !pow2 && !ctx->force_generic && !ctx->no_specialise && !ctx->no_table_form && depth_ok && P.cell_count > 0 && resident && P.lds_nodes > 0) {
-      const uint32_t n_thr = (P.lds_nodes + 7u) >> 3;
+    if (mode != 2 && !counts_out && !pow2 && !ctx->force_generic && !ctx->no_specialise && !ctx->no_table_form && depth_ok && P.cell_count > 0 && P.lds_nodes > 0) {
+      const uint32_t lds_cells = (P.lds_nodes + 7u) >> 3;
+      const uint32_t n_thr = resident ? lds_cells : (lds_cells < tdt::kThrTopCells ? lds_cells : tdt::kThrTopCells);
       uint32_t ic_bits; std::memcpy(&ic_bits, &P.inv_cell_count, 4);
       if (ctx->thr_cc != P.cell_count || ctx->thr_ic_bits != ic_bits || ctx->thr_n != n_thr || !ctx->thr) {
         if (!ctx->thr) TDT_HIP(ctx, hipMalloc((void **)&ctx->thr, ((size_t)tdt::kLdsCells + 1) * 2 * sizeof(float)));
@@ -1375,7 +1382,7 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
         ctx->thr_cc = P.cell_count; ctx->thr_ic_bits = ic_bits; ctx->thr_n = n_thr; ctx->thr_ok = res[0] == 0;
         std::memcpy(&ctx->thr_f0max, &res[1], 4);
       }
-      table_form = ctx->thr_ok && ctx->max_parent_value < n_thr;      // every cell index an x decision can meet has its thresholds
+      table_form = ctx->thr_ok && (!resident || ctx->max_parent_value < n_thr);      // resident: every cell index an x decision can meet has its thresholds
       P.thr = ctx->thr; P.thr_cells = n_thr; P.thr_f0max = ctx->thr_f0max;
     }
     bool launched = false;

@@ -471,6 +471,11 @@ TDT_DEV void build_top_grid(const uint16_t *lds, uint32_t lds_nodes, int depth, 
 constexpr uint32_t kCostStep = 3, kCostEvent = 64;
 constexpr uint32_t kEventWindow = 1024;   // rays after which the adaptive event threshold's running counts are halved
 constexpr int kMemoLevels = 9;
+// levels of the LDS jump table: 4 for trees inside the LDS table, 5 for the others (see Grid<GL>) — except FORM_TABLE trees outside
+// it, which keep 4: the thresholds the table's band is computed from are staged for the first kThrTopCells cells only (levels 1-4
+// of a breadth-first tree: at most 585 cells), beside the 82 KB node table
+__host__ __device__ constexpr int top_grid_levels(bool resident, bool table) { return (resident || table) ? 4 : 5; }
+constexpr uint32_t kThrTopCells = 1024u;
 constexpr int kMemoFirst = 3;       // levels 1..3 = cells 0..72 at most: always inside the LDS table
 
 // treeLookup rc:359-394 specialised for cell_count = 2^k <= 2^22 with inv_cell_count = 2^-k and
@@ -527,7 +532,7 @@ TDT_DEV float brick_q(uint32_t e, float f) { const float V = __uint_as_float((12
 template <bool COUNT, int CL, int DEPTH, bool RESIDENT, bool SAFEV, bool FULL = false, bool BRICK = false, bool TABLE = false>
 TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float fx, float fy, float fz, float &inv_pow_depth,
                               float &gx, float &gy, float &gz, uint32_t &value, NodeMemo<CL> &memo, Counters &cnt) {
-  static_assert(!TABLE || (RESIDENT && SAFEV && !BRICK), "per-cell thresholds: trees inside the LDS table");
+  static_assert(!TABLE || (SAFEV && !BRICK && !FULL), "per-cell thresholds: the resident walk, or (trees outside the LDS table) the jump table's bands only");
   const int depth = DEPTH > 0 ? DEPTH : P.max_depth;
   const float scale_d = __uint_as_float((uint32_t)(127 + depth) << 23);     // 2^depth
   const float Yf = fy * scale_d, Zf = fz * scale_d;                        // exact
@@ -540,7 +545,7 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
   uint32_t qx = 1u, v = 0, code = 1u;                 // qx: x digits below a sentinel bit that counts the levels visited
   const float fx0 = fx;
   bool jumped = false;
-  constexpr int kTableLevels = RESIDENT ? 4 : 5;                      // (see Grid<GL>)
+  constexpr int kTableLevels = top_grid_levels(RESIDENT, TABLE);      // (see Grid<GL>)
   constexpr int kGridLevels = FULL ? DEPTH : kTableLevels;            // levels the jump covers (BRICK builds: never continue after their jump)
   if constexpr (FULL && !COUNT) {
     const float tg = fx0 * (float)(1 << DEPTH);       // exact
@@ -648,6 +653,15 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
       return;
     }
     uint32_t ix; uint32_t bitx;
+    if constexpr (TABLE) {
+      // a cell_count that is not a power of two, tree outside the LDS table: the x index by the formula itself (rc:376-378) — the
+      // thresholds of x_thresholds would cost a dependent load per level here; they serve the jump table's band
+      const float two_cc = (float)(int32_t)((uint32_t)P.cell_count << 1);
+      const float rx = __builtin_rintf(((fv + fx) * P.inv_cell_count) * two_cc + -0.5f);
+      ix = (uint32_t)f2i(rx);
+      const float tx = __builtin_truncf(rx);
+      bitx = ((tx + -(2.0f * __builtin_floorf(tx / 2.0f))) != 0.0f) ? 1u : 0u;
+    } else
     if (SAFEV || __builtin_expect(__ballot(v >= (1u << 22)) == 0ull, 1)) {
       const float q = (fv + fx) - fv;
       const bool a = q > 0.5f, b = (q == 1.0f);

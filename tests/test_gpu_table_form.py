@@ -43,7 +43,7 @@ def test_unusual_index_uniforms_are_refused_not_guessed():
 
 
 SCENES = [("config", 1), ("config", 2), ("gen", 1, 4, 1 << 14, 100, 7), ("gen", 0, 5, 1 << 16, 100, 9), ("gen", 2, 7, 1 << 16, 256, 11),
-          ("gen", 1, 8, 1 << 20, 256, 13), ("demo",)]
+          ("gen", 1, 8, 1 << 20, 256, 13), ("config", 3), ("config", 5), ("gen", 0, 7, 1 << 20, 100, 17), ("gen", 2, 9, 1 << 20, 512, 19), ("demo",)]
 
 
 def _make(spec):
