@@ -1,0 +1,22 @@
+import os, sys, time
+sys.path.insert(0, "/root/repo")
+from tdt4230_project_raytracing_amd import host, rt
+def run(scene, W, H, spp, b, factor, label):
+    cam = host.camera_reference_pose(W, H, spp // factor, b)
+    cam.image_height = H * factor
+    r = rt.Renderer(scene, cam)
+    for fresh in (True, False):
+        for _ in range(5):
+            if fresh: r.ctx.forget_costs()
+            r.dispatch()
+        r.ctx.finish(); t = time.perf_counter()
+        for _ in range(50):
+            if fresh: r.ctx.forget_costs()
+            r.dispatch()
+        r.ctx.finish(); dt = (time.perf_counter() - t) / 50
+        print(f"{label}: {W}x{H*factor} spp {spp//factor} {'history-free' if fresh else 'replay'}: {dt*1e3:.3f} ms", flush=True)
+    r.close()
+scene = host.Scene.demo()
+run(scene, 1280, 720, 4, 6, 1, "demo as is")
+run(scene, 1280, 720, 4, 6, 4, "demo, every sample its own pixel (4x rows, same frustum)")
+run(scene, 1280, 720, 4, 6, 2, "demo, 2 samples per item")
