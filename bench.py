@@ -559,6 +559,28 @@ def reference_default_block(R, args):
            "oracle_check": {"bands": 8, "rows_per_band": 8, "pixels": opx, "mismatched_pixels": bad, "oracle_s": round(tc, 2), "cores": cores,
                             "oracle_value": round(opx * spp / tc / 1e6, 3)},
            "reference_llvmpipe": quoted("llvmpipe_baseline.json", f"config0_spp{spp}")}
+    # ... and the way the reference really drives it (main.rs:486-601): a camera walk, every frame a dispatch with moved uniforms —
+    # W held down at normal speed plus a mouse turn, 60 fps time step, camera.ron's rates.  Such frames reuse the previous frame's
+    # costs by 8x8 tile (the per-pixel order of a still camera would be stale); no frame is forgotten, none is a replay.
+    from tdt4230_project_raytracing_amd import host, rt
+    walker = host.Camera(90.0, wl.IW, aspect_ratio=wl.IW / wl.IH, origin=(0.0, -0.1, -0.3), viewport_height=2.0, samples_per_pixel=spp,
+                         max_bounce=wl.bounce, turn_rate=0.05, normal_speed=0.03, sprint_speed=0.15)
+    torch = R.torch
+    with torch.cuda.stream(R.stream):
+        def walk_frames(n):
+            for _ in range(n):
+                walker.translate("Front", 1.0 / 60.0); walker.turn_yaw(0.2)
+                rt.initial_uniforms(walker.uniforms(), wl.r.shader.program)
+                wl.r.shader.dispatch_compute(wl.dw, wl.dh, 1)
+        walk_frames(5)
+        R.stream.synchronize()
+        t0 = time.perf_counter()
+        walk_frames(steps)
+        R.stream.synchronize()
+        walk_ms = (time.perf_counter() - t0) / steps * 1e3
+    out["camera_walk_ms"] = round(walk_ms, 4)
+    out["camera_walk_note"] = (f"{steps} consecutive frames of a walking, turning camera (main.rs's render loop: uniforms updated, then dispatch_compute), "
+                               "host-side uniform updates included: the reference's interactive case")
     wl.close()
     os.environ["TDT_NO_TABLE_FORM"] = "1"                    # read when a context is created
     try:
