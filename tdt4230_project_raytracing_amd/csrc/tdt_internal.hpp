@@ -61,6 +61,7 @@ struct tdt_ctx {
   int probe_div;                       // TDT_PROBE_DIV: probe samples of a two-phase frame = spp / probe_div (16)
   float order_blend;                   // TDT_ORDER_BLEND: weight of the 8x8-tile mean in a thin (probe) cost estimate
   uint32_t tile_capacity, cost_tiles;  // allocation size (work-groups); number of work-groups slot_cost holds the last dispatch's costs for (0: none)
+  int cost_range[2]; bool order_exact, no_order_reuse;   // sample range of the launch that recorded slot_cost; slot_order was sorted from the costs of that very launch repeated (TDT_NO_ORDER_REUSE=1: sort every frame)
   CostSig cost_sig;                    // what those costs were measured on (camera, octree parameters, buffer versions, partition)
   // miss pre-pass (cameras outside the octree: miss_prepass_kernel): done flag per queue slot, the filtered hand-out order, scratch
   uint8_t *slot_done; uint32_t *slot_live, *filter_counts; uint32_t done_capacity; bool use_done, no_prepass;   // use_done: set for the launches of a frame whose pre-pass ran (TDT_NO_PREPASS=1: never)

@@ -1281,7 +1281,7 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
         if (ctx->slot_cost) (void)hipFree(ctx->slot_cost);
         if (ctx->slot_order) (void)hipFree(ctx->slot_order);
         if (ctx->slot_acc) (void)hipFree(ctx->slot_acc);
-        ctx->slot_cost = ctx->slot_order = ctx->slot_acc = nullptr; ctx->tile_capacity = 0; ctx->cost_tiles = 0;
+        ctx->slot_cost = ctx->slot_order = ctx->slot_acc = nullptr; ctx->tile_capacity = 0; ctx->cost_tiles = 0; ctx->order_exact = false;
         TDT_HIP(ctx, hipMalloc((void **)&ctx->slot_cost, (size_t)t.owned * 1024 * sizeof(uint32_t)));
         TDT_HIP(ctx, hipMalloc((void **)&ctx->slot_order, (size_t)t.owned * 1024 * sizeof(uint32_t)));
         TDT_HIP(ctx, hipMalloc((void **)&ctx->slot_acc, (size_t)t.owned * 1024 * sizeof(uint32_t)));
@@ -1296,6 +1296,15 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
       CostSig sig;
       make_sig(ctx, c, k, img, &sig);
       P.slot_cost = ctx->slot_cost;
+      // The same launch again (same inputs, same sample range) as the one whose costs the current order was built from, those costs
+      // themselves recorded by such a launch: every pixel costs what it did, the sort would reproduce the order it produced last time
+      // (the sums only double) — so a still camera's frames, from the third on, skip the three sort kernels and the cost stores
+      // (1280x720 / 4 spp: 0.46 -> 0.41 ms; the order, a schedule, changes no pixel)
+      const bool same_launch = ctx->cost_tiles == (uint32_t)t.owned && std::memcmp(&sig, &ctx->cost_sig, sizeof sig) == 0 &&
+                               ctx->cost_range[0] == spp_begin && ctx->cost_range[1] == spp_count && ctx->force_smooth < 0;
+      if (same_launch && ctx->order_exact && !ctx->no_order_reuse) {
+        P.slot_order = ctx->slot_order; P.plan = ctx->order_hist + 2048; P.slot_cost = nullptr;
+      } else
       if (ctx->cost_tiles == (uint32_t)t.owned) {
         const int smooth = ctx->force_smooth >= 0 ? ctx->force_smooth : (std::memcmp(&sig, &ctx->cost_sig, sizeof sig) != 0 ? 1 : 0);
         // same inputs again (progressive passes, repeated frames): keep adding to the costs — every pass sharpens the
@@ -1323,14 +1332,17 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
         TDT_HIP(ctx, hipGetLastError());
         ctx->order_parity ^= 1u;                        // (only now: a failed launch leaves the zeroed set in place)
         P.slot_order = ctx->slot_order;
+        ctx->order_exact = same_launch && !smooth && blend == 0.0f;      // built from what this very launch cost last time
       } else {                                        // no usable history: image order, fresh cost array
         TDT_HIP(ctx, hipMemsetAsync(ctx->slot_cost, 0, (size_t)t.owned * 1024 * sizeof(uint32_t), ctx->stream));
         TDT_HIP(ctx, hipMemsetAsync(ctx->slot_acc, 0, (size_t)t.owned * 1024 * sizeof(uint32_t), ctx->stream));
-        ctx->cost_dispatches = 0; ctx->acc_samples = 0;
+        ctx->cost_dispatches = 0; ctx->acc_samples = 0; ctx->order_exact = false;
       }
-      ctx->last_launch_samples = (uint32_t)(spp_count > 0 ? spp_count : 0);
-      ctx->cost_sig = sig;
-      ctx->cost_tiles = (uint32_t)t.owned;            // the kernel launched below records this dispatch's costs
+      if (P.slot_cost) {                              // the kernel launched below records this dispatch's costs
+        ctx->last_launch_samples = (uint32_t)(spp_count > 0 ? spp_count : 0);
+        ctx->cost_sig = sig; ctx->cost_range[0] = spp_begin; ctx->cost_range[1] = spp_count;
+        ctx->cost_tiles = (uint32_t)t.owned;
+      }
     }
   }
   if (t.owned > 0 && mode != 2 && ctx->use_done && !counts_out) {
@@ -1520,6 +1532,7 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
     ctx->no_cost_accum = getenv("TDT_NO_COST_ACCUM") != nullptr;
     ctx->no_two_phase = getenv("TDT_NO_TWO_PHASE") != nullptr;
     ctx->no_prepass = getenv("TDT_NO_PREPASS") != nullptr;
+    ctx->no_order_reuse = getenv("TDT_NO_ORDER_REUSE") != nullptr;
     ctx->no_full = getenv("TDT_NO_FULL_GRID") != nullptr;
     ctx->no_table_form = getenv("TDT_NO_TABLE_FORM") != nullptr;
     ctx->no_bricks = getenv("TDT_NO_BRICKS") != nullptr;
@@ -1985,7 +1998,7 @@ int tdt_dispatch_counted_range(tdt_compute *c, int width, int height, int depth,
 int tdt_forget_costs(tdt_ctx *ctx) {
   if (!ctx) return TDT_ERR_INVALID_VALUE;
   if (ctx->multi) return tdt::multi_forget_costs(ctx);
-  ctx->cost_tiles = 0; ctx->cost_dispatches = 0;      // launch(): "no usable history" -> image order, fresh cost arrays
+  ctx->cost_tiles = 0; ctx->cost_dispatches = 0; ctx->order_exact = false;      // launch(): "no usable history" -> image order, fresh cost arrays
   return TDT_OK;
 }
 
