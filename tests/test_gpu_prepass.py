@@ -117,3 +117,25 @@ def test_prepass_on_a_multi_device_context_and_scaled_octree(oracle):
             assert _eq(r.render(), ref) and _eq(r.render(), ref)
         finally:
             r.close()
+
+
+@pytest.mark.parametrize("cfg,spp,origin", [(2, 16, None), (0, 4, None), (2, 16, (0.9, 0.6, 0.8)), (3, 3, (1.4, 0.2, 0.3))])
+def test_still_camera_frames_reuse_the_order(oracle, cfg, spp, origin, monkeypatch):
+    """From the third identical frame on the sort is skipped and the previous hand-out order is reused (launch(): order_exact) — with
+    and without a filtered order (camera outside), after a two-phase first frame or a one-pass one; then a moved camera, then still again."""
+    scene = host.Scene.config(cfg)
+    cam = host.camera_reference_pose(168, 100, spp, 6) if origin is None else _cam(168, 100, spp, origin, yaw=-130.0 if cfg == 2 else -100.0, pitch=-20.0, fov=70.0)
+    ref = oracle.render(scene, cam, threads=8)
+    r = rt.Renderer(scene, cam)
+    try:
+        for _ in range(5):
+            assert _eq(r.render(), ref)
+        moved = cam.copy()
+        moved.origin[1] += 0.01
+        moved.lower_left_corner[1] += 0.01
+        rt.initial_uniforms(moved, r.shader.program)
+        ref2 = oracle.render(scene, moved, threads=8)
+        for _ in range(4):
+            assert _eq(r.render(), ref2)
+    finally:
+        r.close()
