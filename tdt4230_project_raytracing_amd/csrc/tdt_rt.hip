@@ -932,8 +932,15 @@ __device__ __forceinline__ uint32_t run_cost(uint32_t c) {          // wave-wide
 // pixel's remaining samples will cost than its own few do.  What it buys is the END of the frame: a pixel whose probe samples
 // happened to be cheap no longer starts last and finishes alone (probe order: the last wave ended 8 % after the first).
 __device__ __forceinline__ uint32_t blended_cost(uint32_t a, float blend) {
-  const float tile_mean = (float)run_cost(a) * (1.0f / 64.0f);
-  const float v = (1.0f - blend) * (float)a + blend * tile_mean;
+  // (blend < 0: experiment — shrink towards the tile's MAXIMUM instead of its mean, weight |blend|)
+  float tile_stat;
+  if (blend < 0.0f) {
+    uint32_t m = a;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t q = (uint32_t)__shfl_xor((int)m, o, 64); m = q > m ? q : m; }
+    tile_stat = (float)m; blend = -blend;
+  } else tile_stat = (float)run_cost(a) * (1.0f / 64.0f);
+  const float v = (1.0f - blend) * (float)a + blend * tile_stat;
   return a == 0u ? 0u : (uint32_t)(v < 1.0f ? 1.0f : (v > 4.0e9f ? 4.0e9f : v));     // (0 = never run: stays last)
 }
 __global__ __launch_bounds__(1024) void order_hist_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ acc, uint32_t n, uint32_t *__restrict__ hist, uint32_t g, int smooth, int keep, float blend) {
@@ -947,7 +954,7 @@ __global__ __launch_bounds__(1024) void order_hist_kernel(const uint32_t *__rest
     const uint32_t c = cost[i], before = keep ? acc[i] : 0u, a = before + c < before ? 0xFFFFFFFFu : before + c;
     acc[i] = a;
     if (smooth) { const uint32_t k = order_key(run_cost(a), g); if ((threadIdx.x & 63u) == 0) atomicAdd(&s_bin[k], 64u); }
-    else atomicAdd(&s_bin[order_key(blend > 0.0f ? blended_cost(a, blend) : a, g)], 1u);
+    else atomicAdd(&s_bin[order_key(blend != 0.0f ? blended_cost(a, blend) : a, g)], 1u);
   }
   __syncthreads();
   if (threadIdx.x < 512 && s_bin[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_bin[threadIdx.x]);
@@ -960,7 +967,7 @@ __global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restric
   const uint32_t lo = blockIdx.x * kOrderChunk, hi = lo + kOrderChunk < n ? lo + kOrderChunk : n;
   for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) {
     if (smooth) { const uint32_t k = order_key(run_cost(acc[i]), g); if ((threadIdx.x & 63u) == 0) atomicAdd(&s_bin[k], 64u); }
-    else atomicAdd(&s_bin[order_key(blend > 0.0f ? blended_cost(acc[i], blend) : acc[i], g)], 1u);
+    else atomicAdd(&s_bin[order_key(blend != 0.0f ? blended_cost(acc[i], blend) : acc[i], g)], 1u);
   }
   __syncthreads();
   if (threadIdx.x < 512) {
@@ -976,7 +983,7 @@ __global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restric
       pos = (uint32_t)__shfl((int)pos, 0, 64);
       order[pos + (threadIdx.x & 63u)] = i;
     } else {
-      order[atomicAdd(&s_base[order_key(blend > 0.0f ? blended_cost(acc[i], blend) : acc[i], g)], 1u)] = i;
+      order[atomicAdd(&s_base[order_key(blend != 0.0f ? blended_cost(acc[i], blend) : acc[i], g)], 1u)] = i;
     }
     cost[i] = 0;
     // tile-sum mode = the inputs changed: these costs served once, as a prior for this dispatch's order; the estimate for
