@@ -139,3 +139,20 @@ def test_still_camera_frames_reuse_the_order(oracle, cfg, spp, origin, monkeypat
             assert _eq(r.render(), ref2)
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("env", [{"TDT_NO_COST_ORDER": "1"}, {"TDT_NO_TWO_PHASE": "1"}, {"TDT_NO_ORDER_REUSE": "1"}, {"TDT_NO_SPECIALISE": "1"}])
+def test_prepass_under_the_schedule_switches(oracle, env, monkeypatch):
+    """The filtered hand-out order in image order (no cost feedback at all), without two-phase frames, with a sort every frame, and
+    in front of the general kernel: same bits."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    scene = host.Scene.config(2)
+    cam = _cam(200, 136, 16, (0.9, 0.6, 0.8), yaw=-130.0, pitch=-20.0, fov=70.0)
+    ref = oracle.render(scene, cam, threads=8)
+    r = rt.Renderer(scene, cam)
+    try:
+        for _ in range(4):
+            assert _eq(r.render(), ref)
+    finally:
+        r.close()
