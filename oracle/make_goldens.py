@@ -45,6 +45,13 @@ CASES = {
     # the reference's own MagicaVoxel model (assets/models/monu1_point.ply, 156 942 voxels) through the PLY loader
     # restatement and the octree builder; the built payloads (14 KB compressed) are stored in the fixture
     "monu1_ply_320x240_spp2_b6": (("ply", "monu1_point.ply"), 320, 240, 2, 6, None),
+    # the reference host's own conventions on bigger trees: cell_count = PRE_ALLOCATED_CELLS = 100000 (main.rs:459: not a power of two —
+    # for many cells the x index of treeLookup reads the upper half of the PREVIOUS cell at the bottom of the cell) and a pre-allocated
+    # buffer with a tail of zero nodes (main.rs:339-341); ("config_cc", config, cell_count, zero nodes appended)
+    "config2_cc100000_160x96_spp3_b6": (("config_cc", 2, 100000, 30000), 160, 96, 3, 6, None),
+    "config2_cc100000_on_axes_160x96_spp3_b6": (("config_cc", 2, 100000, 30000), 160, 96, 3, 6, None, (0.0, 0.0, -0.5)),   # rays along cell boundaries: coordinates with f = 0
+    "config3_cc100000_200x120_spp2_b6": (("config_cc", 3, 100000, 0), 200, 120, 2, 6, None),               # outside the LDS table
+    "config2_cc12345_outside_160x96_spp3_b6": (("config_cc", 2, 12345, 0), 160, 96, 3, 6, None, (0.1, 0.05, 0.6)),
 }
 
 
@@ -62,6 +69,8 @@ def make_scene(spec):
     if spec[0] == "ply":
         path = os.path.join(oracle_py.REF_DIR, "assets", "models", spec[1])
         return host.Ply(open(path, "rb").read(), strict_crlf=False).to_scene(max_iter=256)
+    if spec[0] == "config_cc":
+        return host.scene_with_cell_count(host.Scene.config(spec[1]), spec[2], spec[3])
     return host.Scene.generate(*spec[1:])
 
 
@@ -83,7 +92,10 @@ def main():
         pass
     meta_common = {"renderer": gl.renderer(), "cpu_flags": flags, "machine": platform.machine(),
                    "shader": "assets/shaders/raytracer.comp (unmodified, loaded from $REF_DIR at run time)"}
+    only = [a.split("=", 1)[1].split(",") for a in sys.argv[1:] if a.startswith("--only=")]
     for name, case in CASES.items():
+        if only and name not in only[0]:
+            continue
         spec, W, H, spp, bounce, crop = case[:6]
         origin = case[6] if len(case) > 6 else None
         scene = make_scene(spec)
@@ -187,6 +199,7 @@ def present():
 
 if __name__ == "__main__":
     main()
-    math_table()
-    edits()
-    present()
+    if not any(a.startswith("--only=") for a in sys.argv[1:]):
+        math_table()
+        edits()
+        present()

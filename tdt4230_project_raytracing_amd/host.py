@@ -266,6 +266,18 @@ class Scene:
         return sum(a.nbytes for a in self.blobs.values())
 
 
+def scene_with_cell_count(scene, cell_count, zero_tail_nodes=0):
+    """The same tree as a host with other conventions uploads it: Octree::init_global_buffers writes floats[6] = 1.0 / cell_count as
+    f32 and ints[2] = cell_count (octree.rs:49, 79) — the reference's main.rs passes 100000 — and a pre-allocated cells buffer ends in
+    zero nodes (main.rs:339-341)."""
+    blobs = {k: v.copy() for k, v in scene.blobs.items()}
+    blobs[6][6] = np.float32(1.0) / np.float32(cell_count)
+    blobs[7][2] = cell_count
+    if zero_tail_nodes:
+        blobs[0] = np.concatenate([blobs[0], np.zeros(2 * int(zero_tail_nodes), np.uint32)])
+    return Scene(blobs, scene.counts, f"{scene.name}_cc{cell_count}" + (f"_tail{zero_tail_nodes}" if zero_tail_nodes else ""))
+
+
 def _builder(vertical_fov, image_width, aspect_ratio=None, viewport_height=None, origin=None, samples_per_pixel=None,
              max_bounce=None):
     b = CameraBuilderC()

@@ -17,6 +17,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def _scene(z, spec):
     if spec[0] == "config":
         return host.Scene.config(spec[1])
+    if spec[0] == "config_cc":    # the reference host's conventions on a BASELINE scene: (config, cell_count, zero nodes appended)
+        return host.scene_with_cell_count(host.Scene.config(spec[1]), spec[2], spec[3])
     if spec[0] == "ply":          # built from the reference's model file when the fixture was made: payloads stored
         return host.Scene({int(k[5:]): z[k] for k in z.files if k.startswith("blob_")}, name=spec[1])
     return host.Scene.generate(*spec[1:])
