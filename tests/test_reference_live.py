@@ -16,6 +16,20 @@ def test_oracle_vs_reference_shader_fresh_scene(oracle, glref, kind, depth, seed
     assert (got.view(np.uint32) == ref.view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("kind,depth,seed,cc", [(1, 5, 21, 100000), (2, 6, 22, 99999), (0, 7, 23, 100000), (1, 6, 24, 3000)])
+def test_oracle_vs_reference_shader_under_other_cell_counts(oracle, glref, kind, depth, seed, cc):
+    """cell_count as the reference's own host passes it (100000: not a power of two) and neighbours of it: the index arithmetic of
+    treeLookup then reads the previous cell at the bottom of many cells — live against the shader on fresh scenes, rays along cell
+    boundaries included."""
+    scene = host.scene_with_cell_count(host.Scene.generate(kind, depth, 1 << 18, 100, seed), cc, 1000)
+    for origin in (None, (0.0, 0.0, -0.5)):
+        cam = host.camera_reference_pose(96, 64, 2, 5) if origin is None else host.camera_build(
+            90.0, 96, aspect_ratio=1.5, viewport_height=2.0, origin=origin, samples_per_pixel=2, max_bounce=5)
+        ref = glref.render(scene, cam)
+        got = oracle.render(scene, cam, threads=4)
+        assert (got.view(np.uint32) == ref.view(np.uint32)).all()
+
+
 def test_reference_work_group_size_and_layout(glref):
     """compute_shader.rs:18 queries {32,32,1}; the `layout(shared)` blocks are packed like std430,
     which is what the tightly packed host payloads assume (SURVEY.md §7 hard parts)."""
