@@ -21,7 +21,7 @@ def test_oracle_vs_reference_shader_under_other_cell_counts(oracle, glref, kind,
     """cell_count as the reference's own host passes it (100000: not a power of two) and neighbours of it: the index arithmetic of
     treeLookup then reads the previous cell at the bottom of many cells — live against the shader on fresh scenes, rays along cell
     boundaries included."""
-    scene = host.scene_with_cell_count(host.Scene.generate(kind, depth, 1 << 18, 100, seed), cc, 1000)
+    scene = host.scene_with_cell_count(host.Scene.generate(kind, depth, 1 << 20, 100, seed), cc, 1000)
     for origin in (None, (0.0, 0.0, -0.5)):
         cam = host.camera_reference_pose(96, 64, 2, 5) if origin is None else host.camera_build(
             90.0, 96, aspect_ratio=1.5, viewport_height=2.0, origin=origin, samples_per_pixel=2, max_bounce=5)
