@@ -42,6 +42,8 @@ def run(budget=120.0, seed=1, log=print):
         except RuntimeError:
             continue                                                   # scene needs more cells than cell_count
         flavour = int(rng.integers(0, 4))
+        if os.environ.get("FUZZ_BIAS") and rng.random() < 0.6:
+            flavour = 1                                                # FUZZ_BIAS=1: mostly non-power-of-two counts ...
         if flavour == 1:                                               # a cell_count that is not a power of two (the reference's own is 100000)
             scene = with_cell_count(scene, int(rng.choice([100000, 99999, 12345, 65537, 3000, 1000003])) if rng.random() < 0.7 else int(rng.integers(scene.counts["cells"] + 1, 1 << 21)))
         if flavour == 2 or (flavour == 1 and rng.random() < 0.5):      # a pre-allocated cells buffer: a tail of zero nodes (main.rs:339-341)
@@ -49,6 +51,8 @@ def run(budget=120.0, seed=1, log=print):
         W = int(rng.choice([32, 64, 96, 100, 131])); H = int(rng.choice([32, 64, 70, 97]))
         spp = int(rng.choice([1, 2, 5, 16, 33])); bounce = int(rng.choice([1, 3, 8]))
         mode = int(rng.integers(0, 4))
+        if os.environ.get("FUZZ_BIAS") and rng.random() < 0.4:
+            mode = 2                                                   # ... and cameras anywhere (mostly outside: the miss pre-pass)
         if mode == 0:
             cam = host.camera_reference_pose(W, H, spp, bounce)
         else:
