@@ -241,6 +241,11 @@ int tdt_octree_build_from_points(tdt_ctx *ctx, const int32_t *voxels_xyzk, size_
 int tdt_debug_edit_mode(tdt_ctx *ctx, int mode);
 /* which path the last edit dispatch of the context took: 0 none yet, 1 ordered walk, 2 parallel.  Synchronises. */
 int tdt_debug_last_edit_path(tdt_ctx *ctx);
+/* which build of the trace kernel the context's last trace launch ran: out = {form: 0 the literal float index, 1 the exact form of a
+ * power-of-two cell_count, 2 per-cell thresholds (any other count); compile-time depth (0 = the general kernel); tree inside the LDS
+ * table; whole-depth table; bricks; the build that skips multiplications by a scale of 1.0f}.  Every build writes the same pixels; this
+ * lets a test tell a scene that fell back to the general kernel from one that runs its specialised build. */
+int tdt_debug_last_variant(const tdt_ctx *ctx, int out[6]);
 /* lane-utilisation diagnostics of the last tdt_dispatch_counted of this context (32 totals; layout in
  * csrc/trace_device.hpp `Counters`); development aid */
 int tdt_debug_counters(tdt_ctx *ctx, uint64_t out[32]);

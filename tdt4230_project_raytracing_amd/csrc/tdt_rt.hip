@@ -1474,8 +1474,13 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
       if (brick) fn = find_variant(form, P.max_depth, false, false, true, unit);
       if (!fn && full) fn = find_variant(form, P.max_depth, true, true, false, unit);
       if (!fn) fn = find_variant(form, P.max_depth, resident, false, false, unit);
-      if (fn) { hipLaunchKernelGGL(fn, grid, block, 0, ctx->stream, P); launched = true; }
+      if (fn) {
+        hipLaunchKernelGGL(fn, grid, block, 0, ctx->stream, P); launched = true;
+        const int v[6] = {form, P.max_depth, (brick || !resident) ? 0 : 1, (!brick && full) ? 1 : 0, brick ? 1 : 0, unit ? 1 : 0};
+        std::memcpy(ctx->last_variant, v, sizeof v);
+      }
     }
+    if (!launched && mode != 2) { const int v[6] = {pow2 ? tdt::FORM_POW2 : tdt::FORM_LITERAL, 0, 0, 0, 0, 0}; std::memcpy(ctx->last_variant, v, sizeof v); }
 #define TDT_LAUNCH(C) do { if (pow2) hipLaunchKernelGGL((tdt::trace_kernel<C, tdt::FORM_POW2>), grid, block, 0, ctx->stream, P); \
                            else hipLaunchKernelGGL((tdt::trace_kernel<C, tdt::FORM_LITERAL>), grid, block, 0, ctx->stream, P); } while (0)
     if (!launched && counts_out && getenv("TDT_COUNT_SPECIALISED") && pow2 && safev && resident && P.max_depth == 6) {
@@ -2026,6 +2031,16 @@ int tdt_debug_phase_timing(tdt_ctx *ctx, int enable, float ms[3]) {
     for (auto &e : ctx->phase_ev) (void)hipEventDestroy(e);
     ctx->phase_timing = false; ctx->phase_n = 0;
   }
+  return TDT_OK;
+}
+
+/* which build of the trace kernel the last trace launch of the context ran: {form (0 literal, 1 power-of-two, 2 thresholds), compile-time
+ * depth (0: the general kernel), resident, full, brick, unit} — so that tests can tell a scene that silently fell back to the general
+ * kernel from one that runs its specialised build (same pixels either way) */
+int tdt_debug_last_variant(const tdt_ctx *ctx, int out[6]) {
+  if (!ctx || !out) return TDT_ERR_INVALID_VALUE;
+  if (ctx->multi) ctx = tdt::multi_first_member(const_cast<tdt_ctx *>(ctx));
+  std::memcpy(out, ctx->last_variant, 6 * sizeof(int));
   return TDT_OK;
 }
 

@@ -75,6 +75,7 @@ SYMBOLS = [
                                           ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     ("tdt_debug_edit_mode", _I, [_P, _I]),
     ("tdt_debug_last_edit_path", _I, [_P]),
+    ("tdt_debug_last_variant", _I, [_P, ctypes.POINTER(ctypes.c_int)]),
     ("tdt_debug_counters", _I, [_P, ctypes.POINTER(ctypes.c_uint64)]),
     ("tdt_debug_wave_ends", _I, [_P, ctypes.POINTER(ctypes.c_uint64), _I]),
     ("tdt_debug_pixel_log", _I, [_P, ctypes.c_void_p, ctypes.c_size_t]),
@@ -193,6 +194,12 @@ class Context:
         n = ctypes.c_uint64(0)
         self.check(lib().tdt_selftest(self.h, which, ctypes.byref(n)))
         return n.value
+
+    def last_variant(self):
+        """The build of the trace kernel the last trace launch ran: dict(form, depth, resident, full, brick, unit); depth 0 = general kernel."""
+        v = (ctypes.c_int * 6)()
+        self.check(lib().tdt_debug_last_variant(self.h, v))
+        return dict(zip(("form", "depth", "resident", "full", "brick", "unit"), [int(x) for x in v]))
 
     def selftest_index(self, cell_count, inv_cell_count, n_cells, shift=0):
         """(mismatches, shape_ok) of the per-cell x-index thresholds vs the literal formula: every f in [0,1) x every cell < n_cells."""
