@@ -246,6 +246,12 @@ int tdt_debug_last_edit_path(tdt_ctx *ctx);
  * table; whole-depth table; bricks; the build that skips multiplications by a scale of 1.0f}.  Every build writes the same pixels; this
  * lets a test tell a scene that fell back to the general kernel from one that runs its specialised build. */
 int tdt_debug_last_variant(const tdt_ctx *ctx, int out[6]);
+/* pass / lane statistics of the PRODUCT trace kernels (how many traversal and event passes the waves ran, how many lanes were live in
+ * each code region: the STAT_* rows of csrc/tdt_rt.hip) since the last reset — collected only by a -DTDT_STATS build of the library
+ * (tools/loss_budget.py builds one beside the product library; the product library answers TDT_ERR_INVALID_OPERATION).  The first
+ * call switches the collection on; reset != 0 clears the totals after reading them.  out: n_words entries (0: the 32 totals) —
+ * 32 totals, then the time (100 MHz ticks) the first wave met the end of the pixel queue, then up to 8192 per-wave end times. */
+int tdt_debug_stats(tdt_ctx *ctx, uint64_t *out, int n_words, int reset);
 /* lane-utilisation diagnostics of the last tdt_dispatch_counted of this context (32 totals; layout in
  * csrc/trace_device.hpp `Counters`); development aid */
 int tdt_debug_counters(tdt_ctx *ctx, uint64_t out[32]);

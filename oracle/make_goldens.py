@@ -52,12 +52,43 @@ CASES = {
     "config2_cc100000_on_axes_160x96_spp3_b6": (("config_cc", 2, 100000, 30000), 160, 96, 3, 6, None, (0.0, 0.0, -0.5)),   # rays along cell boundaries: coordinates with f = 0
     "config3_cc100000_200x120_spp2_b6": (("config_cc", 3, 100000, 0), 200, 120, 2, 6, None),               # outside the LDS table
     "config2_cc12345_outside_160x96_spp3_b6": (("config_cc", 2, 12345, 0), 160, 96, 3, 6, None, (0.1, 0.05, 0.6)),
+    # round 4 — TURNED cameras: the uniforms the reference's controller sends after turn_yaw / turn_pitch (camera.rs:68-82 ->
+    # raytracer.comp:304-307), all nine components of horizontal / vertical / lower_left_corner non-zero.  The pose is a dict
+    # (origin, yaw, pitch in degrees, vertical fov); the uniforms come from the host mirror of the controller (host.Camera) and are
+    # STORED in the fixture, which the tests feed to the oracle and the kernel as they are ("camera_explicit": the controller's own
+    # arithmetic is not what these fixtures pin — the shader's use of whatever uniforms it is sent is)
+    "demo_turned_inside_160x96_spp4_b6": (("config", 0), 160, 96, 4, 6, None, {"origin": (0.2, -0.1, 0.25), "yaw": 23.0, "pitch": 20.0, "fov": 60.0}),
+    "config2_turned_outside_in_160x96_spp16_b6": (("config", 2), 160, 96, 16, 6, None, {"origin": (0.58, 0.25, 0.66), "yaw": 43.0, "pitch": -25.0, "fov": 60.0}),   # the miss pre-pass decides most pixels; 16 spp: a two-phase frame
+    "config3_cc100000_turned_grazing_200x120_spp3_b8": (("config_cc", 3, 100000, 0), 200, 120, 3, 8, None, {"origin": (-0.5004, 0.21, 0.37), "yaw": -17.0, "pitch": -25.0, "fov": 60.0}),   # along a face of the root cube, tree outside the LDS table
+    "config5_turned_inside_192x108_spp2_b8": (("config", 5), 192, 108, 2, 8, None, {"origin": (0.05, -0.1, 0.3), "yaw": 23.0, "pitch": 8.0, "fov": 60.0}),
+    # ... and one the controller cannot reach (its right vector stays horizontal: horizontal.y is always 0, camera.rs:70) but the shader
+    # takes like any other uniforms: the first pose rolled about its view axis — all NINE components non-zero
+    "demo_rolled_inside_160x96_spp4_b6": (("config", 0), 160, 96, 4, 6, None, {"origin": (0.2, -0.1, 0.25), "yaw": 23.0, "pitch": 20.0, "fov": 60.0, "roll": 31.0}),
 }
 
 
 def make_camera(W, H, spp, bounce, origin=None):
     if origin is None:
         return host.camera_reference_pose(W, H, spp, bounce)
+    if isinstance(origin, dict):                          # a turned camera: the controller's uniforms (host.Camera)
+        c = host.Camera(origin["fov"], W, aspect_ratio=float(np.float32(W) / np.float32(H)), viewport_height=2.0, origin=origin["origin"],
+                        samples_per_pixel=spp, max_bounce=bounce)
+        # the controller turns by 2 * angle * turn_rate radians (camera.rs:46-62; turn_rate 0.025, camera.rs:167)
+        c.turn_yaw(float(np.radians(origin["yaw"])) / 0.05)
+        c.turn_pitch(float(np.radians(origin["pitch"])) / 0.05)
+        u = c.uniforms()
+        if origin.get("roll"):                            # (fp32 throughout; the fixture stores what comes out)
+            f32 = np.float32
+            h, v, o3 = np.array(u.horizontal, f32), np.array(u.vertical, f32), np.array(u.origin, f32)
+            fwd = o3 - h * f32(0.5) - v * f32(0.5) - np.array(u.lower_left_corner, f32)
+            cr, sr = f32(np.cos(np.radians(origin["roll"]))), f32(np.sin(np.radians(origin["roll"])))
+            wh, wv = np.linalg.norm(h).astype(f32), np.linalg.norm(v).astype(f32)
+            hn, vn = h / wh, v / wv
+            h2, v2 = (hn * cr + vn * sr) * wh, (vn * cr - hn * sr) * wv
+            u.horizontal[:] = [float(x) for x in h2]
+            u.vertical[:] = [float(x) for x in v2]
+            u.lower_left_corner[:] = [float(x) for x in (o3 - h2 * f32(0.5) - v2 * f32(0.5) - fwd)]
+        return u
     aspect = float(np.float32(W) / np.float32(H))
     return host.camera_build(90.0, W, aspect_ratio=aspect, viewport_height=2.0, origin=origin,
                              samples_per_pixel=spp, max_bounce=bounce)
@@ -108,6 +139,7 @@ def main():
             data = img
         meta = dict(meta_common)
         meta.update({"scene": list(spec), "W": W, "H": H, "spp": spp, "max_bounce": bounce, "crop": crop, "origin": origin,
+                     "camera_explicit": isinstance(origin, dict),
                      "scene_sha256": scene_digest(scene),
                      "camera": {k: (list(getattr(cam, k)) if hasattr(getattr(cam, k), "__len__") else getattr(cam, k))
                                 for k, _ in host.CameraUniforms._fields_}})

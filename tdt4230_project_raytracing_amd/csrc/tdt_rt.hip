@@ -82,6 +82,27 @@ template <> struct HitOwed<false> {
   TDT_DEV bool new_record() const { return (bits & 2u) != 0u; }
 };
 
+// -DTDT_STATS builds (tools/loss_budget.py; never the product library): what the passes of the product kernels carry — how many
+// traversal / event passes a wave runs and how many lanes are live in each code region — summed per wave in LDS (one lane writes its
+// wave's row) and added to P.stats when the wave ends.  Together with the static instruction counts of the regions
+// (tools/isa_regions.py) this splits the SQ counters' VALU wave-instructions and active lanes by region: profiles/r04_loss_budget.json.
+enum : int { STAT_TRAV_PASS = 0, STAT_TRAV_LANES, STAT_INSIDE_LANES, STAT_ALIVE_LANES, STAT_EVENT_PASS, STAT_EVENT_LANES, STAT_HIT_PASS, STAT_HIT_LANES,
+             STAT_LAMB_PASS, STAT_LAMB_LANES, STAT_METAL_PASS, STAT_METAL_LANES, STAT_DIEL_PASS, STAT_DIEL_LANES, STAT_END_PASS, STAT_END_LANES,
+             STAT_PIXEL_END_PASS, STAT_PIXEL_END_LANES, STAT_FETCH_PASS, STAT_FETCH_LANES, STAT_PRIMARY_PASS, STAT_PRIMARY_LANES,
+             STAT_NEWRAY_PASS, STAT_NEWRAY_LANES, STAT_GATE_WAIT_LANES, STAT_DRAINED_TRAV_PASS, STAT_DRAINED_EVENT_PASS, STAT_LOOP_PASS, STAT_WAVE_TICKS, STAT_WAVES,
+             STAT_T_FIRST, STAT_T_LAST, STAT_COUNT = 32 };
+#ifdef TDT_STATS
+TDT_DEV void stat_add(uint32_t *row, int i, unsigned long long mask) {      // mask: the lanes (of those executing this) that are live in the region
+  const unsigned long long m = __ballot(1);
+  if (mask != 0ull && (threadIdx.x & 63) == (uint32_t)__builtin_ctzll(m)) { row[i] += 1u; row[i + 1] += (uint32_t)__popcll(mask); }
+}
+#define TDT_ST(i, mask) stat_add(s_stat_row, (i), (mask))
+#define TDT_ST1(i, v) do { const unsigned long long m_ = __ballot(1); if ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(m_)) s_stat_row[i] += (uint32_t)(v); } while (0)
+#else
+#define TDT_ST(i, mask) do {} while (0)
+#define TDT_ST1(i, v) do {} while (0)
+#endif
+
 // P.accumulate == 0: the whole of main() rc:234-252; 1: only the sample loop, adding to running sums (a uniform run-time
 // flag, looked at once per pixel, so the scene-specialised variants serve progressive passes too).
 // COUNT: instrumented build that also totals the events defining the algorithmic bytes.
@@ -135,6 +156,13 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   }
   ns.cells = __builtin_amdgcn_make_buffer_rsrc((void *)P.cells, 0, (int)((P.cells_dwords >> 1) << 3), 0x00020000);
   const MatSource ms = material_source(P);
+#ifdef TDT_STATS
+  __shared__ uint32_t s_stats[(TDT_BLOCK / 64) * STAT_COUNT];
+  uint32_t *const s_stat_row = &s_stats[(threadIdx.x >> 6) * STAT_COUNT];
+  if ((threadIdx.x & 63) < STAT_COUNT) s_stat_row[threadIdx.x & 63] = 0u;
+  const unsigned long long stat_t0 = __builtin_amdgcn_s_memrealtime();
+  bool stat_drained = false;
+#endif
   const uint32_t total_slots = (uint32_t)P.owned_tiles * 1024u;
   if (blockIdx.x == 0 && threadIdx.x == 0 && P.queue_next) *P.queue_next = 0u;     // the NEXT launch's queue head (two heads alternate: no memset per launch)
 
@@ -165,12 +193,37 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   // updates those with a dozen s_and / s_andn2 / s_or per pass; as an integer in a VGPR the pass is 16 scalar instructions shorter — which
   // is worth 0.8 % where registers are to spare (the whole-depth-table and LDS-resident builds) and costs 0.5-3 % in the brick builds,
   // which sit at 124-126 of 128 VGPRs: those keep the masks (measured both ways on configs 2 / 3 / 5)
+#ifdef TDT_K2_PROXY
+  HitOwed<false> owed;
+#else
   HitOwed<BRICK> owed;
+#endif
   uint32_t hit_index = 0;
+#ifdef TDT_K2_PROXY
+  float &leaf_box_x = ix, &leaf_box_y = iy, &leaf_box_z = iz;
+#else
   float leaf_box_x = 0.f, leaf_box_y = 0.f, leaf_box_z = 0.f;
+#endif
   Carry pc;
   pc.root = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}; pc.leaf = pc.root; pc.root_t = 0.f;
   const int s_end = P.spp_begin + P.spp_count;
+#if defined(TDT_K2_PROXY) && !defined(TDT_LAZY_ROOT)
+#define TDT_LAZY_ROOT 1
+#endif
+#ifdef TDT_K2_PROXY
+  // SPEED PROXY, NOT A RENDERER (tools/k2_proxy.sh; never the product library): a second path context per lane.  While a lane's active
+  // context waits at the event gate its parked one takes the traversal steps; an event pass serves one waiting context per lane.  Only
+  // the per-RAY state is doubled (and exchanged, v_swap_b32 under the mask of the lanes that switch); everything per PIXEL (sums,
+  // attenuation, sample counter, the pixel itself) is shared by the two contexts, so the image is garbage — but the passes, the lanes in
+  // them and the instructions are those of a two-context kernel whose per-pixel state lives outside the registers, i.e. an upper bound
+  // on what such a kernel could gain (measured before building it).
+  Ray p_r = {0.f, 0.f, 0.f, 0.f, 0.f, 1.f};
+  float p_ix = 0.f, p_iy = 0.f, p_iz = 0.f, p_t_stride = 0.f, p_t_max = 0.f, p_ipd = 0.5f, p_root_t = 0.f;
+  int p_it = 0, p_state = ST_PRIMARY, p_loop = 0;
+  uint32_t p_hit_index = 0, p_owed = 0, k2_passes = 0;
+
+#define TDT_K2_SWAP(a, b) asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b))
+#endif
 
   // adaptive event threshold (wave-uniform).  Model: a traversal pass costs C_t issue slots, an event pass C_e
   // whatever the number of lanes it serves; with threshold T about T/2 lanes idle through the traversal
@@ -189,7 +242,9 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
 #define TDT_TICK(i) do { if (COUNT) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tacc[i] += n_ - tlast; tlast = n_; } } while (0)
   for (;;) {
     if (COUNT) pass_no++;
+    TDT_ST1(STAT_LOOP_PASS, 1);
     // ------------------------------------------------------------ one traversal step rc:410-447
+    TDT_MARK(traversal);
     {
       // Flat form: every lane evaluates the loop condition and the position (the values of lanes that are not traversing
       // are never used), so the step is ONE exec region instead of three nested ones.
@@ -217,11 +272,16 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
         in_box = !((__builtin_fabsf(ez) + __builtin_fabsf(ey)) != -__builtin_fabsf(ex));
       }
       const bool inside = go && in_box;
+      TDT_ST(STAT_TRAV_PASS, __ballot(trav)); TDT_ST1(STAT_INSIDE_LANES, __popcll(__ballot(inside))); TDT_ST1(STAT_ALIVE_LANES, __popcll(__ballot(state != ST_DONE)));
+#ifdef TDT_STATS
+      TDT_ST1(STAT_DRAINED_TRAV_PASS, stat_drained ? 1 : 0);
+#endif
       if (inside) {
         float ugx, ugy, ugz; uint32_t value;
         if (COUNT) cnt.iterations++;
         const bool leaf = POW2 ? tree_lookup_pow2<COUNT, kMemoLevels, DEPTH, RESIDENT, SAFEV, FULL, BRICK, TABLE>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, memo, cnt)
                                : tree_lookup<COUNT>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, cnt);
+        TDT_MARK(traversal_b);
         lane_work += kCostStep + (127u - (__float_as_uint(inv_pow_depth) >> 23));   // + tree levels visited (inv_pow_depth = 2^-levels)
         const float bx = (UNIT ? ugx : ugx * P.scale) + P.min_x, by = (UNIT ? ugy : ugy * P.scale) + P.min_y, bz = (UNIT ? ugz : ugz * P.scale) + P.min_z;
         const float cs0 = UNIT ? inv_pow_depth : P.scale * inv_pow_depth;
@@ -250,9 +310,25 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
 
     TDT_TICK(0);
     // ------------------------------------------------------------ path events
+    TDT_MARK(gate);
+#ifdef TDT_K2_PROXY
+    auto k2_swap = [&]() {      // (executed under the exec mask of the lanes that switch contexts)
+      TDT_K2_SWAP(r.ox, p_r.ox); TDT_K2_SWAP(r.oy, p_r.oy); TDT_K2_SWAP(r.oz, p_r.oz); TDT_K2_SWAP(r.dx, p_r.dx); TDT_K2_SWAP(r.dy, p_r.dy); TDT_K2_SWAP(r.dz, p_r.dz);
+      TDT_K2_SWAP(ix, p_ix); TDT_K2_SWAP(iy, p_iy); TDT_K2_SWAP(iz, p_iz); TDT_K2_SWAP(t_stride, p_t_stride); TDT_K2_SWAP(t_octree_max, p_t_max);
+      TDT_K2_SWAP(inv_pow_depth, p_ipd); TDT_K2_SWAP(it, p_it); TDT_K2_SWAP(state, p_state); TDT_K2_SWAP(loop_count, p_loop); TDT_K2_SWAP(hit_index, p_hit_index);
+      TDT_K2_SWAP(owed.bits, p_owed); TDT_K2_SWAP(pc.root_t, p_root_t);
+      // (the leaf's box lives in ix / iy / iz, dead between the leaf and the next ray: see leaf_box_x)
+    };
+    if (state != ST_TRAVERSE && p_state == ST_TRAVERSE) k2_swap();      // the active context waits (or is done): the parked one takes the steps
+    if (++k2_passes > (8u << 20)) break;                                 // (a proxy must not be able to hang the GPU)
+    const unsigned long long m_trav = __ballot(state == ST_TRAVERSE);
+    const unsigned long long m_event = __ballot(state > ST_TRAVERSE || p_state > ST_TRAVERSE);      // lanes with a context to serve
+    if (m_trav == 0ull && m_event == 0ull) break;
+#else
     const unsigned long long m_trav = __ballot(state == ST_TRAVERSE);
     const unsigned long long m_event = __ballot(state > ST_TRAVERSE);
     if (m_trav == 0ull && m_event == 0ull) break;
+#endif
     w_steps += (uint32_t)__popcll(m_trav);            // lanes that take the next traversal step
     // run the (long, material-divergent) event code only when enough lanes wait for it (a separate
     // threshold for scatter alone was measured: worse at every setting)
@@ -260,9 +336,18 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     // with the lanes still alive so that the survivors do not wait for company that will never come
     const int n_alive = __popcll(m_trav | m_event);
     const int th_now = n_alive == 64 ? threshold : ((threshold * n_alive) >> 6) + 1;
+    TDT_ST1(STAT_GATE_WAIT_LANES, __popcll(m_event));      // (every pass: lanes parked at the gate or about to be served)
     if ((int)__popcll(m_event) < th_now && m_trav != 0ull) { TDT_TICK(1); continue; }
     TDT_TICK(1);
+    TDT_ST(STAT_EVENT_PASS, m_event); TDT_ST(STAT_HIT_PASS, __ballot(state == ST_HIT));
+#ifdef TDT_STATS
+    TDT_ST1(STAT_DRAINED_EVENT_PASS, stat_drained ? 1 : 0);
+#endif
 
+#ifdef TDT_K2_PROXY
+    if (state <= ST_TRAVERSE && p_state > ST_TRAVERSE) k2_swap();        // serve the parked context of lanes whose active one needs nothing
+#endif
+    TDT_MARK(hit_prologue);
     if (COUNT) evpass_no++;
     if (COUNT) { cnt.event_slots += slot64(); cnt.event_active += (state > ST_TRAVERSE); }
     lane_work += (state > ST_TRAVERSE) ? kCostEvent : 0u;
@@ -270,14 +355,27 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     if (state == ST_HIT) {                            // RayColor loop body rc:272-295
       if (COUNT) { cnt.scatter_slots += slot64(); cnt.scatter_active++; }
       const MatRef mat = material_fetch(ms, hit_index);
+      TDT_ST(STAT_LAMB_PASS, __ballot(mat.type == 0u)); TDT_ST(STAT_METAL_PASS, __ballot(mat.type == 1u)); TDT_ST(STAT_DIEL_PASS, __ballot(mat.type == 2u));
+#ifdef TDT_LAZY_ROOT
+      // (experiment, not bit-exact in the stale-record cases: no record is carried — the leaf call site's is this hit's own, the root call
+      // site's is recomputed from the ray and the root entry parameter when a hit needs it)
+      HitTmp k_leaf = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}, k_root = k_leaf;
+      if (owed.new_record()) cube_hit_record(r, t_stride, leaf_box_x, leaf_box_y, leaf_box_z, inv_pow_depth, k_leaf);
+      if (__ballot(!owed.leaf_site()) != 0ull) { if (!owed.leaf_site()) cube_hit_record(r, pc.root_t, P.min_x, P.min_y, P.min_z, P.scale, k_root); }
+      loop_count += 1;
+      const HitTmp &src = owed.leaf_site() ? k_leaf : k_root;
+#else
       if (owed.new_record()) { cube_hit_record(r, t_stride, leaf_box_x, leaf_box_y, leaf_box_z, inv_pow_depth, pc.leaf); if (COUNT) cnt.leaf_records++; }
       loop_count += 1;
       const HitTmp &src = owed.leaf_site() ? pc.leaf : pc.root;
+#endif
       Hit h;
       h.px = src.px; h.py = src.py; h.pz = src.pz; h.nx = src.nx; h.ny = src.ny; h.nz = src.nz; h.ff = src.ff;
       h.index = hit_index;
       Ray nr; float tr, tg, tb;
-      if (scatter<COUNT>(ms, r, h, mat, nr, tr, tg, tb, cnt)) {
+      const bool scattered = scatter<COUNT>(ms, r, h, mat, nr, tr, tg, tb, cnt);
+      TDT_MARK(hit_epilogue);
+      if (scattered) {
         ar = ar * tr; ag = ag * tg; ab = ab * tb;
         r = nr;
         // rc:271: the bounce limit ends the path here and now — ST_END is handled further down in this same pass; going
@@ -288,6 +386,8 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       }
     }
     TDT_TICK(2);
+    TDT_MARK(end_of_path);
+    TDT_ST(STAT_END_PASS, __ballot(state == ST_END));
     if (state == ST_END) {                            // rc:297-301, rc:246
       float cr, cg, cb;
       if (loop_count > 0) { cr = ar; cg = ag; cb = ab; }
@@ -300,9 +400,12 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       s++;
       if (s < s_end) state = ST_PRIMARY;
       else {
+        TDT_MARK(pixel_end);
+        TDT_ST(STAT_PIXEL_END_PASS, __ballot(1));
         float4 *dst = reinterpret_cast<float4 *>(P.image) + pix;
         if (P.accumulate) {
           *dst = make_float4(sr, sg, sb, 0.f);
+#ifndef TDT_LAZY_ROOT
           if (P.carry && !P.carry_final) {           // (the last launch of a two-phase frame: nobody will read the records again)
             float4 *c = reinterpret_cast<float4 *>(P.carry) + pix * 4;
             c[0] = make_float4(pc.root.nx, pc.root.ny, pc.root.nz, pc.root.px);
@@ -310,6 +413,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
             c[2] = make_float4(pc.leaf.nx, pc.leaf.ny, pc.leaf.nz, pc.leaf.px);
             c[3] = make_float4(pc.leaf.py, pc.leaf.pz, pc.leaf.ff ? 1.f : 0.f, 0.f);
           }
+#endif
         } else {
           const float n = (float)P.samples_per_pixel;   // rc:249-251
           float4 o;
@@ -333,6 +437,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       }
     }
     TDT_TICK(3);
+    TDT_MARK(fetch);
     {                                                 // next pixel from the block queue
       // Slots are drawn from the queue up to 64 at a time — one atomic and one coalesced read of the hand-out order per wave
       // and refill — into buf_slot (lane i holds the i-th slot of the batch) and dealt to the lanes that ask, in lane
@@ -340,6 +445,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       // the round trip every time ONE lane finished a pixel: 9 % of the frame.)
       bool want = state == ST_FETCH;
       unsigned long long m = __ballot(want);
+      TDT_ST(STAT_FETCH_PASS, m);
       while (m != 0ull) {
         if (buf_next >= buf_count) {                  // refill: guided self-scheduling — 64 slots while plenty are left,
           // fewer towards the end of the queue (slots parked in one wave's batch are out of reach of idle lanes elsewhere)
@@ -353,6 +459,9 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
           buf_slot = ((threadIdx.x & 63u) < chunk && bq < total_slots) ? (P.slot_order ? P.slot_order[bq] : bq) : 0xFFFFFFFFu;
           buf_next = 0u; buf_count = chunk;
           if (COUNT && base + chunk > total_slots) wave_drained = true;
+#ifdef TDT_STATS
+          if (base + chunk > total_slots && !stat_drained) { stat_drained = true; if (P.stats && (threadIdx.x & 63) == 0) atomicMin(&P.stats[STAT_COUNT], __builtin_amdgcn_s_memrealtime()); }      // [STAT_COUNT]: when the first wave met the end of the queue
+#endif
         }
         const uint32_t rank = (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
         const uint32_t avail = buf_count - buf_next;
@@ -377,12 +486,14 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
               if (P.accumulate && P.spp_begin != 0) {    // (a range that starts at sample 0 starts from nothing)
                 const float4 acc = *(reinterpret_cast<const float4 *>(P.image) + pix);
                 sr = acc.x; sg = acc.y; sb = acc.z;
+#ifndef TDT_LAZY_ROOT
                 if (P.carry) {
                   const float4 *c = reinterpret_cast<const float4 *>(P.carry) + pix * 4;
                   const float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
                   pc.root = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z != 0.f}; pc.root_t = c1.w;
                   pc.leaf = {c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z != 0.f};
                 }
+#endif
               }
               if (s < s_end) state = ST_PRIMARY;
               else if (!P.accumulate) {               // zero samples: main() still stores sqrt(0/0) clamped
@@ -396,11 +507,14 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       }
     }
     TDT_TICK(4);
+    TDT_MARK(primary);
+    TDT_ST(STAT_PRIMARY_PASS, __ballot(state == ST_PRIMARY));
     if (state == ST_PRIMARY) {                        // rc:240-245
       r = primary_ray(P, x, y, s);
       loop_count = 0; ar = 1.f; ag = 1.f; ab = 1.f;
       state = ST_NEWRAY;
     }
+    TDT_MARK(threshold);
     w_rays += (uint32_t)__popcll(__ballot(state == ST_NEWRAY));
     if (P.event_threshold <= 0) {
       if (w_rays > kEventWindow) { w_steps >>= 1; w_rays >>= 1; }   // sliding window: the mix of pixels a wave sees changes over a frame
@@ -412,6 +526,8 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       threshold = w_rays < 256u ? 24 : (th < 2 ? 2 : th);
     }
     TDT_TICK(5);
+    TDT_MARK(newray);
+    TDT_ST(STAT_NEWRAY_PASS, __ballot(state == ST_NEWRAY));
     if (state == ST_NEWRAY) {                         // while-condition rc:271 + OctreeHit prologue rc:399-408
       if (!(loop_count < P.max_bounce)) state = ST_END;
       else {
@@ -426,7 +542,9 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
         const float t_exit = hw_min(hw_min(hw_min(mxx, inf), mxy), mxz);
         t_octree_max = inf;
         if (t_exit >= t_enter) {
+#ifndef TDT_LAZY_ROOT
           cube_hit_record(r, t_enter, P.min_x, P.min_y, P.min_z, P.scale, pc.root);
+#endif
           pc.root_t = t_enter;
           t_octree_max = t_exit;
         }
@@ -437,8 +555,21 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       }
     }
     TDT_TICK(6);
+    TDT_MARK(loop_tail);
   }
+  TDT_MARK(after_loop);
 #undef TDT_TICK
+#ifdef TDT_STATS
+  if (P.stats) {
+    const unsigned long long stat_t1 = __builtin_amdgcn_s_memrealtime();
+    const uint32_t lane = threadIdx.x & 63u;
+    if (lane < (uint32_t)STAT_WAVE_TICKS) { const uint32_t v = s_stat_row[lane]; if (v) atomicAdd(&P.stats[lane], (unsigned long long)v); }
+    if (lane == 0) { atomicAdd(&P.stats[STAT_WAVE_TICKS], stat_t1 - stat_t0); atomicAdd(&P.stats[STAT_WAVES], 1ull);
+                     atomicMin(&P.stats[STAT_T_FIRST], stat_t0); atomicMax(&P.stats[STAT_T_LAST], stat_t1);
+                     const uint32_t w = blockIdx.x * (TDT_BLOCK / 64) + (threadIdx.x >> 6);      // per-wave end times (100 MHz ticks) of the last launch
+                     if (w < 8192u) P.stats[STAT_COUNT + 1 + w] = stat_t1; }
+  }
+#endif
 
   if (COUNT) {
     // wave timeline (diagnostics): [18] earliest start, [19] latest end, [20] sum of wave end times, [21] waves
@@ -1223,6 +1354,9 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     P.event_k = ctx->event_k > 0.0f ? ctx->event_k : (r < 0.10f ? 0.10f : (r > 0.35f ? 0.35f : r));
   }
 
+#ifdef TDT_STATS
+  P.stats = (mode == 0 || mode == 1) && !counts_out && !(ctx->probe_launch && getenv("TDT_STATS_SKIP_PROBE")) ? ctx->stats : nullptr;   // (SKIP_PROBE: the main launch of a two-phase frame alone)
+#endif
   TDT_HIP(ctx, hipSetDevice(ctx->device));
   if (ctx->ssbo[TDT_SLOT_CELLS]->bytes > 0xFFFFFFF8ull)
     return fail(ctx, TDT_ERR_INVALID_VALUE, "cells buffer larger than 4 GiB is not addressable by the shader's 32-bit offsets");
@@ -1538,7 +1672,7 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
   if (!ctx) return fail(nullptr, TDT_ERR_HIP, "out of host memory");
   ctx->device = device_id;
   for (auto &s : ctx->ssbo) s = nullptr;
-  ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr; ctx->queue = nullptr; ctx->packed = nullptr; ctx->packed_of = nullptr; ctx->packed_version = 0; ctx->present = nullptr; ctx->present_bytes = 0; ctx->frame_carry = nullptr; ctx->frame_carry_bytes = 0; ctx->probe_launch = false; ctx->phase_timing = false; ctx->phase_n = 0; ctx->pixel_log = nullptr; ctx->pixel_log_u32 = 0; ctx->slot_cost = ctx->slot_acc = ctx->slot_order = ctx->order_hist = nullptr; ctx->tile_capacity = ctx->cost_tiles = 0; ctx->cost_dispatches = 0;
+  ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr; ctx->queue = nullptr; ctx->packed = nullptr; ctx->packed_of = nullptr; ctx->packed_version = 0; ctx->present = nullptr; ctx->present_bytes = 0; ctx->frame_carry = nullptr; ctx->frame_carry_bytes = 0; ctx->probe_launch = false; ctx->phase_timing = false; ctx->phase_n = 0; ctx->pixel_log = nullptr; ctx->pixel_log_u32 = 0; ctx->stats = nullptr; ctx->slot_cost = ctx->slot_acc = ctx->slot_order = ctx->order_hist = nullptr; ctx->tile_capacity = ctx->cost_tiles = 0; ctx->cost_dispatches = 0;
   { const char *nc = getenv("TDT_NO_COST_ORDER"); ctx->no_cost_order = nc && nc[0] == '1';
     const char *fs = getenv("TDT_ORDER_SMOOTH"); ctx->force_smooth = fs ? atoi(fs) : -1;
     ctx->no_cost_accum = getenv("TDT_NO_COST_ACCUM") != nullptr;
@@ -1587,6 +1721,7 @@ void tdt_ctx_destroy(tdt_ctx *ctx) {
   if (ctx->slot_acc) (void)hipFree(ctx->slot_acc);
   if (ctx->order_hist) (void)hipFree(ctx->order_hist);
   if (ctx->pixel_log) (void)hipFree(ctx->pixel_log);
+  if (ctx->stats) (void)hipFree(ctx->stats);
   if (ctx->present) (void)hipFree(ctx->present);
   if (ctx->frame_carry) (void)hipFree(ctx->frame_carry);
   if (ctx->slot_done) (void)hipFree(ctx->slot_done);
@@ -2042,6 +2177,33 @@ int tdt_debug_last_variant(const tdt_ctx *ctx, int out[6]) {
   if (ctx->multi) ctx = tdt::multi_first_member(const_cast<tdt_ctx *>(ctx));
   std::memcpy(out, ctx->last_variant, 6 * sizeof(int));
   return TDT_OK;
+}
+
+/* -DTDT_STATS builds of the library only (tools/loss_budget.py): pass / lane statistics of the product trace kernels launched on this
+ * context since the last reset (the STAT_* rows of tdt_rt.hip); the first call switches the collection on.  The product library
+ * answers TDT_ERR_INVALID_OPERATION. */
+int tdt_debug_stats(tdt_ctx *ctx, uint64_t *out, int n_words, int reset) {
+  if (!ctx) return TDT_ERR_INVALID_VALUE;
+  if (ctx->multi) ctx = tdt::multi_first_member(ctx);
+#ifdef TDT_STATS
+  TDT_HIP(ctx, hipSetDevice(ctx->device));
+  const bool fresh = ctx->stats == nullptr;
+  constexpr size_t kStatWords = tdt::STAT_COUNT + 1 + 8192;      // totals, the time the queue ran dry, per-wave end times
+  if (fresh) TDT_HIP(ctx, hipMalloc((void **)&ctx->stats, kStatWords * sizeof(unsigned long long)));
+  TDT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const size_t n_out = n_words > 0 ? ((size_t)n_words < kStatWords ? (size_t)n_words : kStatWords) : (size_t)tdt::STAT_COUNT;
+  if (out && !fresh) TDT_HIP(ctx, hipMemcpy(out, ctx->stats, n_out * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  else if (out) std::memset(out, 0, n_out * sizeof(uint64_t));
+  if (reset || fresh) {
+    std::vector<unsigned long long> init(kStatWords, 0ull);
+    init[tdt::STAT_T_FIRST] = ~0ull; init[tdt::STAT_COUNT] = ~0ull;
+    TDT_HIP(ctx, hipMemcpy(ctx->stats, init.data(), kStatWords * sizeof(unsigned long long), hipMemcpyHostToDevice));
+  }
+  return TDT_OK;
+#else
+  (void)out; (void)n_words; (void)reset;
+  return fail(ctx, TDT_ERR_INVALID_OPERATION, "pass statistics need a -DTDT_STATS build of the library (tools/loss_budget.py)");
+#endif
 }
 
 /* lane-utilisation diagnostics of the last tdt_dispatch_counted on this context (see Counters) */

@@ -15,6 +15,13 @@
 namespace tdt {
 
 #define TDT_DEV __device__ __forceinline__
+// -DTDT_MARKERS (tools/isa_regions.py; never the product library): assembler comments at the boundaries of the trace kernel's code regions,
+// so that the compiler's output can be cut into traversal step / gate / scatter branches / end of path / fetch / primary ray / new ray
+#ifdef TDT_MARKERS
+#define TDT_MARK(name) asm volatile("; TDT_MARK " #name)
+#else
+#define TDT_MARK(name) do {} while (0)
+#endif
 
 // how a kernel build computes treeLookup's x index (rc:376-378): the float formula as written; the exact-comparison form for
 // cell_count = 2^k (tree_lookup_pow2); the same walk with per-cell thresholds for any other cell_count (XThreshold)
@@ -706,6 +713,7 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
     fx = f_fract_nonneg(fx0 * __uint_as_float((uint32_t)(127 + l) << 23));   // fract(c * 2^l): next level's coordinate
   };
   constexpr int kFirstAfterJump = (kGridLevels > kMemoFirst ? kGridLevels : kMemoFirst) + 1;
+  TDT_MARK(walk);
   if (!jumped) {                                      // (wave-uniform) the levels a jump would have covered
 #pragma unroll
     for (int l = 1; l <= kMemoFirst; l++) {
@@ -791,7 +799,13 @@ TDT_DEV bool scatter(const MatSource &ms, const Ray &r, const Hit &h, const MatR
   float nx = h.nx, ny = h.ny, nz = h.nz;
   out.ox = h.px; out.oy = h.py; out.oz = h.pz;
   if (COUNT) { cnt.lambertian += (type == 0); cnt.metal += (type == 1); cnt.dielectric += (type == 2); cnt.unknown += ((uint32_t)type > 2u); }
+#ifdef TDT_SHARED_RAND2
+  // Rand(hit.point.xy) is the first draw of BOTH ScatterMetal (rc:488 via RandVec3) and ScatterDielectric (rc:513): one evaluation for the lanes of either kind
+  float rnd_md = 0.0f;
+  if (type == 1 || type == 2) rnd_md = rand2(h.px, h.py);
+#endif
   if (type == 0) {   // ScatterLambertian rc:470-482, constructFrisvad rc:453-468, SampleGGXVNDF rc:27-49
+    TDT_MARK(lambert);
     float mx, my, mz; float rs;
     unit_or_normalised(nx, ny, nz, mx, my, mz);
     bool sing = nz < -0.9999f;
@@ -848,12 +862,17 @@ TDT_DEV bool scatter(const MatSource &ms, const Ray &r, const Hit &h, const MatR
     return true;
   }
   if (type == 1) {   // ScatterMetal rc:484-491, RandInHemisphere rc:106-115 (one cube sample, as compiled)
+    TDT_MARK(metal);
     float mx, my, mz; float rs;
     unit_or_normalised(nx, ny, nz, mx, my, mz);
     float dt = ((mz * dz + my * dy) + mx * dx) * 2.0f;
     float rx = dx + -(dt * mx), ry = dy + -(dt * my), rz = dz + -(dt * mz);
     const float fuzz = m_fuzz;
+#ifdef TDT_SHARED_RAND2
+    float hx = -1.0f + 2.0f * rnd_md;
+#else
     float hx = -1.0f + 2.0f * rand2(h.px, h.py);
+#endif
     float hy = -1.0f + 2.0f * rand2(h.px + hx, h.py + hx);
     float hz = -1.0f + 2.0f * rand2(h.px + hy, h.py + hy);
     bool same = -(hz * nz + hy * ny) < hx * nx;
@@ -866,6 +885,7 @@ TDT_DEV bool scatter(const MatSource &ms, const Ray &r, const Hit &h, const MatR
     return -(qz * nz + qy * ny) < qx * nx;
   }
   if (type == 2) {   // ScatterDielectric rc:499-522, reflectance rc:494-497
+    TDT_MARK(dielectric);
     float ratio = h.ff ? q_rcp(ir) : ir;
     float pz_ = dz * nz, py_ = dy * ny, px_ = dx * nx;
     float cos_t = f_min((-pz_ + -py_) + -px_, 1.0f);
@@ -873,7 +893,11 @@ TDT_DEV bool scatter(const MatSource &ms, const Ray &r, const Hit &h, const MatR
     bool cannot = 1.0f < ratio * sin_t;
     float q = schlick_q(ratio);
     float r0 = q * q;
+#ifdef TDT_SHARED_RAND2
+    float rnd = rnd_md;
+#else
     float rnd = rand2(h.px, h.py);
+#endif
     float refl = pow_poly(1.0f + -cos_t, 5.0f) * (1.0f + -r0) + r0;
     float dn = (pz_ + py_) + px_;
     float ox_, oy_, oz_;

@@ -77,6 +77,7 @@ SYMBOLS = [
     ("tdt_debug_last_edit_path", _I, [_P]),
     ("tdt_debug_last_variant", _I, [_P, ctypes.POINTER(ctypes.c_int)]),
     ("tdt_debug_counters", _I, [_P, ctypes.POINTER(ctypes.c_uint64)]),
+    ("tdt_debug_stats", _I, [_P, ctypes.POINTER(ctypes.c_uint64), _I, _I]),
     ("tdt_debug_wave_ends", _I, [_P, ctypes.POINTER(ctypes.c_uint64), _I]),
     ("tdt_debug_pixel_log", _I, [_P, ctypes.c_void_p, ctypes.c_size_t]),
     ("tdt_selftest", _I, [_P, _I, ctypes.POINTER(ctypes.c_uint64)]),
@@ -200,6 +201,21 @@ class Context:
         v = (ctypes.c_int * 6)()
         self.check(lib().tdt_debug_last_variant(self.h, v))
         return dict(zip(("form", "depth", "resident", "full", "brick", "unit"), [int(x) for x in v]))
+
+    STAT_NAMES = ("trav_pass", "trav_lanes", "inside_lanes", "alive_lanes", "event_pass", "event_lanes", "hit_pass", "hit_lanes", "lamb_pass", "lamb_lanes",
+                  "metal_pass", "metal_lanes", "diel_pass", "diel_lanes", "end_pass", "end_lanes", "pixel_end_pass", "pixel_end_lanes", "fetch_pass", "fetch_lanes",
+                  "primary_pass", "primary_lanes", "newray_pass", "newray_lanes", "gate_wait_lanes", "drained_trav_pass", "drained_event_pass", "loop_pass",
+                  "wave_ticks", "waves", "t_first", "t_last")
+
+    def stats(self, reset=True):
+        """Pass / lane statistics of the product trace kernels since the last reset (a -DTDT_STATS build of the library only)."""
+        n = 32 + 1 + 8192
+        v = (ctypes.c_uint64 * n)()
+        self.check(lib().tdt_debug_stats(self.h, v, n, 1 if reset else 0))
+        d = dict(zip(self.STAT_NAMES, [int(x) for x in v[:32]]))
+        d["t_queue_dry"] = int(v[32])
+        d["wave_ends"] = [int(x) for x in v[33:33 + min(int(v[29]), 8192)]]      # (waves: row 29)
+        return d
 
     def selftest_index(self, cell_count, inv_cell_count, n_cells, shift=0):
         """(mismatches, shape_ok) of the per-cell x-index thresholds vs the literal formula: every f in [0,1) x every cell < n_cells."""

@@ -25,7 +25,16 @@ def _scene(z, spec):
 
 
 def _camera(meta):
-    """main.rs:165-168's camera for the fixture's size, optionally moved to the fixture's origin."""
+    """main.rs:165-168's camera for the fixture's size, optionally moved to the fixture's origin; a turned camera (round 4): the
+    uniforms the fixture stores, as the reference shader was sent them."""
+    if meta.get("camera_explicit"):
+        u = host.CameraUniforms()
+        for k, v in meta["camera"].items():
+            if isinstance(v, list):
+                getattr(u, k)[:] = v
+            else:
+                setattr(u, k, v)
+        return u
     if meta.get("origin") is None:
         return host.camera_reference_pose(meta["W"], meta["H"], meta["spp"], meta["max_bounce"])
     aspect = float(np.float32(meta["W"]) / np.float32(meta["H"]))
@@ -57,6 +66,31 @@ def test_gpu_bit_exact_vs_reference_render(name):
     golden = z["image"]
     eq = (img.view(np.uint32) == golden.view(np.uint32)).all(axis=2)
     assert eq.all(), f"{int((~eq).sum())} pixels differ (max |d| {np.nanmax(np.abs(img - golden)):.3g}; tolerance of the north star: 1e-4)"
+
+
+@pytest.mark.parametrize("name", [n for n in CASES if "_turned_" in n or "_rolled_" in n])
+@pytest.mark.parametrize("switch", ["TDT_NO_PREPASS", "TDT_NO_TWO_PHASE", "TDT_NO_SPECIALISE"])
+def test_gpu_turned_cameras_vs_reference_render_under_switches(name, switch, monkeypatch):
+    """The turned-camera fixtures (every component of horizontal / vertical / lower_left_corner non-zero, except horizontal.y, which the
+    reference's controller keeps at 0 — camera.rs:70 — and only the rolled fixture sets) against the reference render with the miss pre-pass off (every pixel through the trace kernel), in one pass, and through the general kernel; and the
+    replay of the frame under the defaults."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    scene, cam, golden = _scene(z, meta["scene"]), _camera(meta), z["image"]
+    comps = [c for k in ("horizontal", "vertical", "lower_left_corner") for c in meta["camera"][k]]
+    assert sum(abs(c) > 1e-3 for c in comps) >= (9 if "_rolled_" in name else 8), "not a turned camera"
+    r = rt.Renderer(scene, cam)
+    try:
+        r.render()
+        assert _eq(r.render(), golden), "replay under the defaults"
+    finally:
+        r.close()
+    monkeypatch.setenv(switch, "1")
+    r = rt.Renderer(scene, cam)
+    try:
+        assert _eq(r.render(), golden), switch
+    finally:
+        r.close()
 
 
 @pytest.mark.parametrize("world", [2, 3, 8])

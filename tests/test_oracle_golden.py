@@ -25,7 +25,16 @@ def _scene(z, spec):
 
 
 def _camera(meta):
-    """main.rs:165-168's camera for the fixture's size, optionally moved to the fixture's origin."""
+    """main.rs:165-168's camera for the fixture's size, optionally moved to the fixture's origin; a turned camera (round 4): the
+    uniforms the fixture stores, as the reference shader was sent them."""
+    if meta.get("camera_explicit"):
+        u = host.CameraUniforms()
+        for k, v in meta["camera"].items():
+            if isinstance(v, list):
+                getattr(u, k)[:] = v
+            else:
+                setattr(u, k, v)
+        return u
     if meta.get("origin") is None:
         return host.camera_reference_pose(meta["W"], meta["H"], meta["spp"], meta["max_bounce"])
     aspect = float(np.float32(meta["W"]) / np.float32(meta["H"]))

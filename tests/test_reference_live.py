@@ -30,6 +30,23 @@ def test_oracle_vs_reference_shader_under_other_cell_counts(oracle, glref, kind,
         assert (got.view(np.uint32) == ref.view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("cfg,origin,yaw,pitch,fov", [(0, (0.2, -0.1, 0.25), -17.0, 8.0, 60.0), (2, (0.62, 0.3, 0.7), 43.0, -20.0, 60.0),
+                                                       (1, (-0.7, 0.9, 0.6), -57.0, -40.0, 60.0)])
+def test_oracle_vs_reference_shader_turned_camera(oracle, glref, cfg, origin, yaw, pitch, fov):
+    """Turned cameras (camera.rs:68-82: every component of horizontal / vertical / lower_left_corner non-zero but horizontal.y, which the
+    controller keeps at 0), inside the octree and outside looking in: the uniforms of the host's controller mirror, whatever their
+    last bit, through the shader and the oracle.  (The controller turns by 2 * angle * turn_rate radians, turn_rate 0.025.)"""
+    scene = host.Scene.config(cfg)
+    c = host.Camera(fov, 96, aspect_ratio=1.5, viewport_height=2.0, origin=origin, samples_per_pixel=3, max_bounce=5)
+    c.turn_yaw(float(np.radians(yaw)) / 0.05)
+    c.turn_pitch(float(np.radians(pitch)) / 0.05)
+    cam = c.uniforms()
+    assert sum(abs(x) > 1e-3 for v in (cam.horizontal, cam.vertical, cam.lower_left_corner) for x in v) >= 8
+    ref = glref.render(scene, cam)
+    got = oracle.render(scene, cam, threads=4)
+    assert (got.view(np.uint32) == ref.view(np.uint32)).all()
+
+
 def test_reference_work_group_size_and_layout(glref):
     """compute_shader.rs:18 queries {32,32,1}; the `layout(shared)` blocks are packed like std430,
     which is what the tightly packed host payloads assume (SURVEY.md §7 hard parts)."""

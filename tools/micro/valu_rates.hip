@@ -49,6 +49,12 @@ __global__ __launch_bounds__(1024) void k(float *out, int iters) {
         if (OP == 29) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "s"(c));
         if (OP == 30) asm volatile("v_mul_f32 %0, 2.0, %0" : "+v"(a[i]));
         if (OP == 31) asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(u[i]) : "v"(u[(i + 1) & 7]) : "vcc");
+        if (OP == 36) asm volatile("v_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[(i + 1) & 7]));
+        if (OP == 37) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+        if (OP == 38) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+        if (OP == 39) asm volatile("v_rsq_f32 %0, %0" : "+v"(a[i]));
+        if (OP == 40) asm volatile("v_mul_f32 %0, %0, %1\n v_min_f32 %2, %2, %3" : "+v"(a[i]), "+v"(a[(i + 4) & 7]) : "v"(b), "v"(c));
+        if (OP == 41) asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_add_f32 %2, %2, %3" : "+v"(a[i]), "+v"(a[(i + 4) & 7]) : "v"(b), "v"(c));
         if (OP == 17) asm volatile("s_and_b64 s[20:21], s[20:21], s[22:23]" : : : "s20", "s21", "scc");   // scc: the loop branch reads it
       }
     }
@@ -83,6 +89,7 @@ int main() {
   run<18>("v_cndmask e64 sgpr", d); run<19>("v_max_f32", d); run<20>("v_sub_f32", d); run<21>("v_mov_b32", d); run<22>("v_or3_b32", d);
   run<23>("v_lshlrev_b32", d); run<24>("v_min_u32", d); run<25>("v_floor_f32", d); run<26>("v_cvt_u32_f32", d); run<27>("v_lshl_add_u32", d);
   run<28>("v_sqrt_f32", d); run<29>("v_fma_f32 sgpr", d); run<30>("v_mul_f32 const", d); run<31>("v_addc_co_u32", d); run<0>("v_fma_f32 again", d);
+  run<36>("v_swap_b32", d); run<37>("v_max3_f32", d); run<38>("v_med3_f32", d); run<39>("v_rsq_f32", d); run<40>("mul + min (2 instr)", d); run<41>("cndmask + add (2 instr)", d);
   run<32>("cmp vcc+cndmask (2 instr)", d); run<33>("cmp sgpr+cndmask64 (2)", d); run<34>("cmp,add,cndmask (3)", d); run<35>("cmp,nop1,cndmask", d);
   return 0;
 }
