@@ -55,6 +55,7 @@ def parse_args(argv=None):
                     help="N=1 only: a step = one PROGRESSIVE frame of passes x spp samples per pixel (configs[4] is 16 x 64): "
                          "running sums and hit-record carry through HBM, one resolve at the end (bit-identical to one pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the weak-scaled side block (N x the pixel rows)")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaled 8K block (BASELINE configs[3])")
     ap.add_argument("--no-target", action="store_true", help="skip the target_4k block (BASELINE configs[2], the north-star roofline config)")
     ap.add_argument("--no-reference-default", action="store_true", help="skip the reference_default block (demo scene, 1280x720, 4 spp)")
@@ -247,6 +248,13 @@ def strong_summary(ms_per_frame, trace_ms_per_rank, one_gpu_ms, one_gpu_source, 
             "backend": backend, "ranks_seen": int(ranks_seen)}
 
 
+def headline_summary(value_n, value_1, world):
+    """The N > 1 headline against the same frame on one GPU: value(N) / value(1) IS the strong-scaling speed-up."""
+    return {"scaling": "strong", "n_gpus": int(world), "value": round(value_n, 2), "one_gpu_value": round(value_1, 2),
+            "speedup_vs_1gpu": round(value_n / value_1, 3) if value_1 else None,
+            "efficiency_note": "speedup_vs_1gpu / n_gpus is the strong-scaling efficiency (the driver computes its own from the per-N lines)"}
+
+
 def rendezvous_only():
     import torch
     import torch.distributed as dist
@@ -266,8 +274,12 @@ def rendezvous_only():
     dist.destroy_process_group()
     if rank == 0:
         trace = [float(v) for v in tr]
+        # the N > 1 headline's arithmetic on the same synthetic times: a frame of 1000 "samples" takes sum(trace) ms on one GPU and
+        # max(trace) ms sharded, so value(N) / value(1) must equal the strong block's speed-up
+        value_1, value_n = 1000.0 / sum(trace), 1000.0 / max(trace)
         print(json.dumps({"rendezvous": world, "rank_sum": t[0].item(), "ranks_seen": int(t[1].item()),
-                          "strong": strong_summary(max(trace), trace, sum(trace), "synthetic (sum of the per-rank times)", "gloo", seen)}), flush=True)
+                          "strong": strong_summary(max(trace), trace, sum(trace), "synthetic (sum of the per-rank times)", "gloo", seen),
+                          "headline_scaling": headline_summary(value_n, value_1, world)}), flush=True)
 
 
 # ------------------------------------------------------------------------------------------------ a rank ----------
@@ -456,6 +468,18 @@ def measure_phases(wl, n=5):
     return [float(v) for v in acc / n]
 
 
+def library_probe_samples(spp):
+    """Probe samples of a two-phase frame, by the rule tdt_ctx_create / dispatch_frame apply (csrc/tdt_rt.hip): max(spp / TDT_PROBE_DIV, 1),
+    the divisor 16 unless the environment holds a value in [2, 64] — so that the counted sample range is the one whose launch is timed."""
+    try:
+        div = int(os.environ.get("TDT_PROBE_DIV", "16"))
+    except ValueError:
+        div = 16
+    if not 2 <= div <= 64:
+        div = 16
+    return max(spp // div, 1)
+
+
 def nominal_roofline(R, wl, cfg, phase, frame_kernel_ms):
     """The `roofline` object for a workload's dominant launch: algorithmic bytes (counted by the instrumented build, untimed) over
     its duration, against the HBM peak — nominal — with the physical (VALU) bound quoted beside it."""
@@ -466,7 +490,7 @@ def nominal_roofline(R, wl, cfg, phase, frame_kernel_ms):
     kernel_ms, kernel_note, main_read = frame_kernel_ms, "whole dispatch (one launch)", read_bytes
     if phase is not None and phase[0] > 0:
         # a two-phase frame: the dominant launch is the main one (samples [spp/16, spp)); count ITS algorithmic events
-        probe = spp // 16
+        probe = library_probe_samples(spp)
         with torch.cuda.stream(R.stream):
             c = torch.zeros((IH, IW, 16), dtype=torch.float32, device=R.dev)
             wl.full.zero_()
@@ -482,6 +506,7 @@ def nominal_roofline(R, wl, cfg, phase, frame_kernel_ms):
     valu, _ = quoted_valu(wkey)
     return {"bound": NOMINAL_BOUND, "bound_note": NOMINAL_NOTE,
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "frac_physical": (physical_roofline(wkey) or {}).get("frac"),      # beside the nominal figure: VALU issue x lanes, the bound the kernel runs against (see `physical`)
             "traffic": traffic, "traffic_note": "measured HBM bytes of the same launch (rocprofv3 TCC counters, profiles/traffic.json): << algorithmic",
             "physical": physical_roofline(wkey),
             "kernel": "tdt::trace_kernel<false, ...> (COUNT = false: the product build)", "kernel_launch": kernel_note,
@@ -578,6 +603,20 @@ def reference_default_block(R, args):
         walk_frames(steps)
         R.stream.synchronize()
         walk_ms = (time.perf_counter() - t0) / steps * 1e3
+    # stand still (the order-reuse state: from the third identical frame on the sort is skipped), then move: the first moved frame
+    # must not fall back to image order (round 3's advice: the reuse state used to leave all-zero costs behind)
+    with torch.cuda.stream(R.stream):
+        ms_moved = []
+        for _ in range(max(steps // 10, 3)):
+            for _ in range(5):
+                wl.r.shader.dispatch_compute(wl.dw, wl.dh, 1)
+            R.stream.synchronize()
+            t0 = time.perf_counter()
+            walk_frames(1)
+            R.stream.synchronize()
+            ms_moved.append((time.perf_counter() - t0) * 1e3)
+    out["still_then_move_ms"] = round(sorted(ms_moved)[len(ms_moved) // 2], 4)
+    out["still_then_move_note"] = "median of the first MOVED frame after five frames of a still camera (which reuse their hand-out order): ordered by the tile sums of the still frames' costs"
     out["camera_walk_ms"] = round(walk_ms, 4)
     out["camera_walk_note"] = (f"{steps} consecutive frames of a walking, turning camera (main.rs's render loop: uniforms updated, then dispatch_compute), "
                                "host-side uniform updates included: the reference's interactive case")
@@ -617,7 +656,10 @@ def main():
     R = Rank(args)
     world, rank = R.world, R.rank
     args.gpus = world
-    scaling = "strong" if args.config == 4 else (args.scaling or "weak")
+    # N > 1: the headline is STRONG scaling of the metric's own frame (1080p / 64 spp sharded over the ranks; N = 1 is that frame on one
+    # GPU, so a scaling curve read from `value` starts at the single-GPU line); the weak-scaled figure (N x the pixel rows) and the 8K
+    # frame of BASELINE configs[3] are side blocks (`weak`, `strong`).  --scaling weak restores round 3's headline.
+    scaling = "strong" if args.config == 4 else (args.scaling or ("strong" if world > 1 else "weak"))
     rows_factor = world if (world > 1 and scaling == "weak") else 1
     if args.passes > 1 and R.sharded:
         raise SystemExit("--passes is a single-GPU option")
@@ -649,6 +691,26 @@ def main():
     gather_ms = Workload.mean_ms(wl.gather_events) if R.sharded else None
     assemble_ms = Workload.mean_ms(wl.assemble_events) if (R.sharded and rank == 0) else None
     rank_trace_ms = R.gather_floats(frame_kernel_ms)
+
+    # ---- N > 1, strong headline: the same frame on ONE GPU in this run (rank 0 alone), and the weak-scaled figure as a side block ----
+    headline_scaling = weak = None
+    if world > 1 and scaling == "strong" and args.config != 4 and not progressive:
+        one_sec = None
+        if rank == 0:
+            ow = Workload(R, args.config, spp=args.spp, alone=True)
+            one_sec, one_px = ow.run(max(args.steps // 2, 1), 1, fresh)
+            ow.close()
+        R.fence()
+        if rank == 0:
+            headline_scaling = headline_summary(value, one_px * spp / one_sec / 1e6, world)
+            headline_scaling["one_gpu_source"] = "rank 0 alone, same run, same schedule"
+        if not args.no_weak:
+            ww = Workload(R, args.config, spp=args.spp, rows_factor=world)
+            wsec, wpx = ww.run(max(args.steps // 2, 1), 1, fresh)
+            weak = {"workload": ww.desc + f"; x{world} pixel rows over the same frustum", "image": [ww.IW, ww.IH], "written_pixels": int(wpx), "ms_per_step": round(wsec * 1e3, 4),
+                    "value": round(wpx * spp / wsec / 1e6, 2), "unit": "Mray-samples/s", "scaling": "weak",
+                    "note": "every rank keeps one N = 1 frame of work (round 3's headline at N > 1)"}
+            ww.close()
 
     # phases of a history-free frame (probe / main / resolve) from events recorded inside the library, a few more frames
     phase = measure_phases(wl, 5) if (fresh and rank == 0 and not R.sharded) else None
@@ -725,9 +787,10 @@ def main():
         "metric": "Mray-samples/sec at 1080p/64spp/depth-8" if args.config == 2 and spp == 64 and args.passes == 1 else f"Mray-samples/sec (config {args.config}, {spp * args.passes} spp" + (f" as {args.passes} progressive passes" if args.passes > 1 else "") + ")",
         "value": round(value, 2), "unit": "Mray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": scaling if world > 1 else "weak",
+        "scaling": scaling if world > 1 else "weak",      # (N = 1: nothing is sharded; the contract's default label)
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": desc + (f"; x{rows_factor} pixel rows over the same frustum (weak scaling)" if rows_factor > 1 else ""),
+        "config": {"workload": desc + (f"; x{rows_factor} pixel rows over the same frustum (weak scaling)" if rows_factor > 1 else "") +
+                               (f"; ONE frame sharded over {world} ranks (strong scaling)" if (world > 1 and rows_factor == 1) else ""),
                    "image": [IW, IH], "dispatch": [dw, dh, 1], "written_pixels": int(total_pixels), "spp": spp * args.passes,
                    "passes": args.passes,
                    "max_bounce": wl.bounce, "octree_max_depth": scene.max_depth, "octree_cells": scene.counts["cells"],
@@ -744,6 +807,8 @@ def main():
                    "gather_ms": round(gather_ms, 4) if gather_ms is not None else None,
                    "assemble_ms": round(assemble_ms, 4) if assemble_ms is not None else None,
                    "partition": f"32x32 work-groups dealt round-robin over {world} rank(s)" + ("; one RCCL gather + de-interleave per step" if R.sharded else "")},
+        "headline_scaling": headline_scaling,
+        "weak": weak,
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
         "target_4k": target_4k,

@@ -178,7 +178,9 @@ int tdt_assemble_tiles(tdt_compute *c, const void *gathered, int world, int tile
  * device memory; NULL = start from / discard the initial state). */
 int tdt_dispatch_accumulate(tdt_compute *c, int width, int height, int depth, int spp_begin, int spp_count,
                             void *carry_device_ptr);
-/* image = clamp(sqrt(sum / total_spp), 0, 1), alpha = 1: raytracer.comp:249-251 */
+/* image = clamp(sqrt(sum / total_spp), 0, 1), alpha = 1: raytracer.comp:249-251 — EVERY covered pixel of the bound image, whatever its
+ * alpha (a pixel no pass wrote resolves from the zeros or whatever the caller put there).  (Inside tdt_dispatch_compute, and only for a
+ * frame whose miss pre-pass ran, the library's own resolve leaves the pixels that pass finished — alpha 1 — alone.) */
 int tdt_dispatch_resolve(tdt_compute *c, int width, int height, int depth, int total_spp);
 /* Instrumented dispatch (measurement only, slower): same image as tdt_dispatch_compute, and
  * returns event totals: [0] pixels written, [1] OctreeHit calls, [2] traversal iterations,

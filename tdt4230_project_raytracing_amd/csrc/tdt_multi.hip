@@ -361,7 +361,7 @@ static int multi_frame(tdt_compute *c, int what, int width, int height, int dept
   if (rc != TDT_OK) return rc;
   for (int i = 0; i < n; i++) {
     rc = member_launch(front, c, i, what, width, height, depth, spp_begin, spp_count, use_carry, total_spp);
-    if (rc != TDT_OK) { abandon_frame(front, i); return rc; }
+    if (rc != TDT_OK) { abandon_frame(front, i + 1); return rc; }      // (member i may have kernels in flight already: its stream is drained too)
   }
   if (what == 1) { M.acc_tiles = tpm; return TDT_OK; }   // running sums stay in the tile buffers until the resolve
   rc = gather_and_assemble(front, c, img, width, height, depth);

@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const TraceParams P) {
   if (!pixel_of_thread(P, x, y, pix)) return;
   float4 *dst = reinterpret_cast<float4 *>(P.image) + pix;
   float4 a = *dst;
-  if (a.w != 0.f) return;                             // running sums carry alpha 0; a pixel that already holds its colour (alpha 1: the miss pre-pass finished it) is left alone
+  if (P.carry_final && a.w != 0.f) return;            // (frames whose miss pre-pass ran: launch() sets the flag) running sums carry alpha 0; a pixel the pre-pass finished holds its colour, alpha 1, and is left alone
   const float n = (float)P.total_spp;
   float4 o;
   o.x = f_min(f_max(__builtin_sqrtf(a.x / n), 0.f), 1.f);
@@ -1332,6 +1332,7 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
   P.metal = (const uint32_t *)ctx->ssbo[TDT_SLOT_METAL]->dev; P.metal_dwords = dwords(ctx->ssbo[TDT_SLOT_METAL]);
   P.dielectric = (const uint32_t *)ctx->ssbo[TDT_SLOT_DIELECTRIC]->dev; P.dielectric_dwords = dwords(ctx->ssbo[TDT_SLOT_DIELECTRIC]);
   P.image = img->dev; P.carry = (float *)carry; P.carry_final = ctx->carry_final ? 1 : 0;
+  if (mode == 2) P.carry_final = ctx->use_done ? 1 : 0;      // resolve: skip the pixels the frame's miss pre-pass finished (only then: tdt_dispatch_resolve on its own resolves every pixel)
   Cover k = cover_of(c, width, height);
   Tiles t = tiles_of(c, k);
   P.cover_w = k.cover_w; P.cover_h = k.cover_h;
@@ -1396,7 +1397,12 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
     // LDS-table image of the bound cells buffer (rebuilt only when the buffer or its contents changed)
     const tdt_buffer *cb = ctx->ssbo[TDT_SLOT_CELLS];
     if (!ctx->packed) TDT_HIP(ctx, hipMalloc((void **)&ctx->packed, (size_t)tdt::kLdsCells * 8 * sizeof(uint16_t)));
-    if (!ctx->queue) { TDT_HIP(ctx, hipMalloc((void **)&ctx->queue, 2 * sizeof(unsigned int))); TDT_HIP(ctx, hipMemsetAsync(ctx->queue, 0, 2 * sizeof(unsigned int), ctx->stream)); ctx->queue_parity = 0; }
+    if (!ctx->queue) {
+      TDT_HIP(ctx, hipMalloc((void **)&ctx->queue, 2 * sizeof(unsigned int)));
+      const hipError_t e = hipMemsetAsync(ctx->queue, 0, 2 * sizeof(unsigned int), ctx->stream);
+      if (e != hipSuccess) { (void)hipFree(ctx->queue); ctx->queue = nullptr; return hip_fail(ctx, e, "pixel-queue heads"); }      // (never a queue with undefined heads)
+      ctx->queue_parity = 0;
+    }
     P.lds_nodes = buf_nodes < tdt::kLdsCells * 8u ? (buf_nodes & ~7u) : tdt::kLdsCells * 8u;
     if (ctx->packed_of != cb || ctx->packed_version != cb->version) {
       if (!ctx->scan) TDT_HIP(ctx, hipMalloc((void **)&ctx->scan, 4 * sizeof(uint32_t)));
@@ -1447,6 +1453,13 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
         P.slot_order = ctx->slot_order; P.plan = ctx->order_hist + 2048; P.slot_cost = nullptr;
       } else
       if (ctx->cost_tiles == (uint32_t)t.owned) {
+        if (ctx->order_exact) {
+          // leaving the reuse state (the camera moved after standing still, another sample range): the launches that reused the order
+          // recorded no costs and the last sort zeroed cost[], but acc[] still holds the sums that order was sorted from — they are the
+          // prior for this launch (the tile sums of a moved camera's frame; a sort from all-zero costs would be image order)
+          TDT_HIP(ctx, hipMemcpyAsync(ctx->slot_cost, ctx->slot_acc, (size_t)t.owned * 1024 * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+          ctx->order_exact = false;
+        }
         const int smooth = ctx->force_smooth >= 0 ? ctx->force_smooth : (std::memcmp(&sig, &ctx->cost_sig, sizeof sig) != 0 ? 1 : 0);
         // same inputs again (progressive passes, repeated frames): keep adding to the costs — every pass sharpens the
         // estimate of what a pixel costs; otherwise start over
@@ -1470,8 +1483,17 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
         }
         hipLaunchKernelGGL(tdt::order_scatter_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, ctx->slot_acc, n_slots,
                            plan + 4, hist + 512, ctx->slot_order, og, smooth, blend);
-        TDT_HIP(ctx, hipGetLastError());
-        ctx->order_parity ^= 1u;                        // (only now: a failed launch leaves the zeroed set in place)
+        {
+          const hipError_t e = hipGetLastError();
+          if (e != hipSuccess) {
+            // a launch of the sequence failed: the histogram may be half filled and the other counter set half zeroed — clear both and
+            // drop the history, so that the next frame starts from image order instead of scattering through a dirty prefix
+            (void)hipMemsetAsync(ctx->order_hist, 0, (2048 + 4 + 512) * sizeof(uint32_t), ctx->stream);
+            ctx->cost_tiles = 0; ctx->order_exact = false; ctx->order_parity = 0;
+            return hip_fail(ctx, e, "cost-order sort");
+          }
+        }
+        ctx->order_parity ^= 1u;                        // (only now: the plan kernel of this pass zeroed the other set)
         P.slot_order = ctx->slot_order;
         ctx->order_exact = same_launch && !smooth && blend == 0.0f;      // built from what this very launch cost last time
       } else {                                        // no usable history: image order, fresh cost array

@@ -45,6 +45,16 @@ def test_self_launch_spawns_ranks_that_meet():
     st = j["strong"]
     assert st["backend"] == "gloo" and st["ranks_seen"] == 3
     assert st["imbalance"] == 1.5 and st["speedup_vs_1gpu"] == 2.0 and st["one_gpu_ms"] == 60.0
+    # ... and the N > 1 HEADLINE is strong scaling of one frame: value(N) / value(1) is that same speed-up
+    h = j["headline_scaling"]
+    assert h["scaling"] == "strong" and h["n_gpus"] == 3 and h["speedup_vs_1gpu"] == st["speedup_vs_1gpu"]
+    assert abs(h["value"] / h["one_gpu_value"] - h["speedup_vs_1gpu"]) < 2e-3
+
+
+def test_headline_summary_is_value_ratio():
+    h = bench.headline_summary(25000.0, 6400.0, 4)
+    assert h["scaling"] == "strong" and h["speedup_vs_1gpu"] == round(25000.0 / 6400.0, 3) and h["one_gpu_value"] == 6400.0
+    assert bench.parse_args(["--gpus", "4"]).scaling is None                   # default: strong at N > 1 (decided from the world size), weak label at N = 1
 
 
 def test_strong_summary_fields():
@@ -77,7 +87,7 @@ def test_a_failing_rank_fails_the_launch():
 @pytest.mark.gpu
 def test_bench_gpus_2_self_launched_on_one_gpu():
     """`python bench.py --gpus 2 --backend gloo --steps 1 --warmup 1` as a fresh child: rc 0 and one JSON line that carries the
-    weak-scaled headline, the strong 8K block with its per-rank times, and the single-process (multi-device context) block."""
+    strong-scaled headline (the metric's frame sharded over the ranks) with the weak-scaled side block, the strong 8K block with its per-rank times, and the single-process (multi-device context) block."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "1",
                         "--strong-steps", "1"], env=env, capture_output=True, text=True, timeout=900)
@@ -85,8 +95,11 @@ def test_bench_gpus_2_self_launched_on_one_gpu():
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0 and j["config"]["image"] == [1920, 2160]
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0 and j["config"]["image"] == [1920, 1080]      # the metric's own frame, sharded
     assert len(j["config"]["trace_ms_per_rank"]) == 2 and j["config"]["gather_ms"] is not None
+    h = j["headline_scaling"]
+    assert h["scaling"] == "strong" and h["n_gpus"] == 2 and abs(j["value"] / h["one_gpu_value"] - h["speedup_vs_1gpu"]) < 2e-3
+    assert j["weak"]["image"] == [1920, 2160] and j["weak"]["scaling"] == "weak" and j["weak"]["value"] > 0
     s = j["strong"]
     assert s["image"] == [7680, 4320] and s["spp"] == 64 and s["written_pixels"] == 7680 * 4320 and len(s["trace_ms_per_rank"]) == 2
     assert s["backend"] == "gloo" and s["ranks_seen"] == 2 and s["imbalance"] >= 1.0 and s["speedup_vs_1gpu"] > 0 and "rank 0 alone" in s["one_gpu_source"]

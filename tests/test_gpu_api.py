@@ -93,6 +93,45 @@ def test_gpu_turned_cameras_vs_reference_render_under_switches(name, switch, mon
         r.close()
 
 
+def test_resolve_on_its_own_resolves_every_pixel():
+    """tdt_dispatch_resolve is main()'s sqrt / clamp / store for EVERY covered pixel (include/tdt_rt.h), whatever alpha the caller's
+    running sums carry — only the library's own resolve of a frame whose miss pre-pass ran skips the pixels that pass finished."""
+    import torch
+    scene = host.Scene.config(1)
+    cam = host.camera_reference_pose(64, 64, 4, 2)
+    buf = torch.empty((64, 64, 4), dtype=torch.float32, device="cuda:0")
+    buf[..., 0], buf[..., 1], buf[..., 2], buf[..., 3] = 1.0, 0.25, 9.0, 1.0      # "sums" with a non-zero alpha
+    torch.cuda.synchronize()
+    r = rt.Renderer(scene, cam, image_ptr=buf.data_ptr())
+    try:
+        r.shader.dispatch_resolve(65, 65, 1, 4)
+        r.ctx.finish()
+    finally:
+        r.close()
+    got = buf.cpu().numpy()
+    assert np.allclose(got[..., 0], 0.5) and np.allclose(got[..., 1], 0.25) and (got[..., 2] == 1.0).all() and (got[..., 3] == 1.0).all()
+
+
+def test_first_moved_frame_after_a_still_camera_keeps_a_prior(oracle):
+    """Frames of a still camera reuse their hand-out order (no sort, no cost stores) from the third on; the first frame after that with
+    other inputs must still be the right pixels — and is ordered from the still frames' sums (bench: reference_default.still_then_move_ms)."""
+    scene = host.Scene.config(2)
+    c = host.Camera(90.0, 160, aspect_ratio=160 / 96, origin=(0.0, -0.1, -0.3), viewport_height=2.0, samples_per_pixel=4, max_bounce=5)
+    r = rt.Renderer(scene, c.uniforms())
+    try:
+        for _ in range(5):
+            still = r.render()
+        c.translate("Front", 0.5); c.turn_yaw(3.0)
+        rt.initial_uniforms(c.uniforms(), r.shader.program)
+        moved = r.render()
+        again = r.render()
+    finally:
+        r.close()
+    assert _eq(still, oracle.render(scene, host.Camera(90.0, 160, aspect_ratio=160 / 96, origin=(0.0, -0.1, -0.3), viewport_height=2.0, samples_per_pixel=4, max_bounce=5).uniforms(), threads=8))
+    ref = oracle.render(scene, c.uniforms(), threads=8)
+    assert _eq(moved, ref) and _eq(again, ref)
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_partition_tile_buffers_and_assemble(oracle, world):
     """Every rank's tile buffer, gathered and de-interleaved by tdt_assemble_tiles, equals the one-rank image."""

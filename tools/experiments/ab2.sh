@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/ab2.sh "<label>|<ENV=..> <ENV=..>|<lib.so or ->" ...   -> bench each variant: history-free ms, replay ms, phases
+# usage: tools/experiments/ab2.sh "<label>|<ENV=..> <ENV=..>|<lib.so or ->" ...   -> bench each variant: history-free ms, replay ms, phases
 # BENCH_ARGS selects the config (default: the bench workload)
 for V in "$@"; do
   IFS='|' read -r LABEL ENVS LIB <<< "$V"

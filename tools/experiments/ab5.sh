@@ -4,5 +4,5 @@ for C in 2 3 5; do
   ARGS=("product c$C|X=1|-")
   for n in "$@"; do ARGS+=("$n c$C|X=1|build_ab/lib_$n.so"); done
   ARGS+=("product c$C|X=1|-")
-  BENCH_ARGS="--config $C --no-target --no-reference-default" STEPS=8 tools/ab2.sh "${ARGS[@]}"
+  BENCH_ARGS="--config $C --no-target --no-reference-default" STEPS=8 tools/experiments/ab2.sh "${ARGS[@]}"
 done

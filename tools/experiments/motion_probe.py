@@ -2,7 +2,7 @@
 """How well does last frame's cost order serve a MOVING camera?  Renders a walk (translate + yaw per frame, camera.ron
 rates, 60 fps time step) and prints per-frame kernel time next to the static steady state and to image order."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tdt4230_project_raytracing_amd import host, rt
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 W, H, spp, bounce = 1920, 1080, 64, {2: 8, 3: 16, 5: 8}.get(cfg, 8)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/pmc.sh <outdir-name>  (runs two PMC passes of one bench step; summaries under gpurun_out/<name>)
+# usage: tools/experiments/pmc.sh <outdir-name>  (runs two PMC passes of one bench step; summaries under gpurun_out/<name>)
 N=$1; shift
 export TMPDIR=/tmp
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_INSTS_SALU --kernel-trace --output-format csv -d gpurun_out/$N/a -- python bench.py --steps 1 --warmup 2 --no-cpu-baseline "$@" > gpurun_out/$N.a.log 2>&1 &&

@@ -3,7 +3,7 @@
 TAG=$1; export TMPDIR=/tmp
 mkdir -p gpurun_out/$TAG
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/stats -- python bench.py --steps 20 --warmup 1 --no-cpu-baseline > gpurun_out/$TAG/bench_stats.log 2>&1
-tools/pmc.sh $TAG/pmc > /dev/null 2>&1
+tools/experiments/pmc.sh $TAG/pmc > /dev/null 2>&1
 tools/traffic.sh $TAG/traffic > /dev/null 2>&1
 tools/traffic.sh $TAG/traffic_c3 --config 3 > /dev/null 2>&1
 tools/traffic.sh $TAG/traffic_c5 --config 5 > /dev/null 2>&1

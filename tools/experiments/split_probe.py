@@ -2,7 +2,7 @@
 """The gain to expect from making every sample (or pair of samples) of a low-spp frame its own queue item: the same frustum with k x the
 pixel rows at spp / k — the same samples, each an independent item ("measured and rejected in round 3")."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tdt4230_project_raytracing_amd import host, rt
 def run(scene, W, H, spp, b, factor, label):
     cam = host.camera_reference_pose(W, H, spp // factor, b)

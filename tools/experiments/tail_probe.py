@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How much of a frame is end-of-kernel tail?  Same frustum, k x the pixel rows: time per pixel row should stay flat."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tdt4230_project_raytracing_amd import host, rt
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2

@@ -3,7 +3,7 @@
 exists: a 1-spp frame of the same view first (its per-pixel costs become 8x8-tile sums, because the next frame's inputs — spp —
 differ), then the 4-spp frame in that tile order; only the second is timed (device events)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tdt4230_project_raytracing_amd import host, rt
 scene = host.Scene.demo()

@@ -3,7 +3,7 @@
 previous dispatch (useless under motion), costs recorded -> remaining samples in the cost order of THIS frame's probe
 (existing accumulate / carry / resolve path; generic MODE-1 kernels, so compare only among the rows printed here)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tdt4230_project_raytracing_amd import host, rt
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
