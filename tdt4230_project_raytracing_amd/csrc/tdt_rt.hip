@@ -61,6 +61,23 @@ TDT_DEV uint32_t wave_sum(uint32_t v) {
   return v;
 }
 
+#ifdef TDT_MEMCARRY
+// The call sites' carried hit records (see Carry) live in MEMORY, 64 B per pixel, not in 15 registers per lane: what a call site last
+// produced is read back only when a hit needs a record its own ray did not write (a slab test that missed: rare), so the registers were
+// held for the whole frame for the sake of a path taken by a handful of rays.  Layout of a pixel's block (float4 x 4):
+//   [0] = (o.x, o.y, o.z, d.x), [1] = (d.y, d.z, -, t) : the last ray whose ROOT slab test hit and its entry parameter — the root call site's
+//         record is a pure function of them (cube_hit_record on the root cube), recomputed when a hit at the first lookup needs it;
+//         d = 0 (no normalised direction is): no such ray yet, the record is the zeros main() starts from.  [1].w doubles as root_t.
+//   [2], [3] = the leaf call site's last record, as computed (n, p, front_face).
+// Stores are fire-and-forget (the block stays in L2 while its pixel is traced); the rare read-back waits for the wave's own stores and
+// bypasses the L1.
+TDT_DEV float4 ld_carry(const float4 *p) {
+  float4 v;
+  asm volatile("s_waitcnt vmcnt(0)\n\tglobal_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+#endif
+
 // Lane states of the flattened path tracer.  The reference's loop nest
 //   for sample { while bounce { for traversal-step { for level } } }        (rc:238,271,410,372)
 // is run per lane as a state machine, so lanes of one wave can be in different samples /
@@ -196,7 +213,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
 #ifdef TDT_K2_PROXY
   HitOwed<false> owed;
 #else
-  HitOwed<BRICK> owed;
+  HitOwed<BRICK || DEPTH == 0> owed;      // (the general kernel, with its nine-level memo, sits at the register cap like the brick builds)
 #endif
   uint32_t hit_index = 0;
 #ifdef TDT_K2_PROXY
@@ -240,6 +257,19 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   // 4 pixel fetch, 5 primary ray + threshold, 6 new-ray prologue -> counters[24..30]
   unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
 #define TDT_TICK(i) do { if (COUNT) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tacc[i] += n_ - tlast; tlast = n_; } } while (0)
+  // The octree's minimum corner in VGPRs (builds with registers to spare): a VALU instruction with an SGPR operand issues at half rate on
+  // gfx950 (tools/micro/pipe_model.hip: v_add_f32 with an SGPR source 4.2 cycles, with VGPR sources 2.7), and the traversal step reads
+  // these three twice each.  (asm: the compiler would fold a plain copy back into the scalar operand.)
+  float vmin_x, vmin_y, vmin_z;
+  if (BRICK || DEPTH == 0) { vmin_x = P.min_x; vmin_y = P.min_y; vmin_z = P.min_z; }      // (the brick builds and the general kernel have no register to spare)
+  else asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=v"(vmin_x), "=v"(vmin_y), "=v"(vmin_z) : "s"(P.min_x), "s"(P.min_y), "s"(P.min_z));
+  // The lanes in ST_TRAVERSE and in an event state as wave masks, carried from pass to pass: a traversal step only moves lanes out of
+  // the first set into the second, so the masks after the step are mask algebra on the step's own conditions — no compare of `state`
+  // in a pass that runs no event code (each v_cmp is a half-rate instruction, and the pass is bound by those: tools/micro/pipe_model.hip).
+  // th_now: the event threshold scaled by the lanes still alive — they only retire in the fetch code, so it is computed after an event
+  // pass, not before every gate.
+  unsigned long long k_trav = 0ull, k_event = ~0ull;       // (every lane starts in ST_FETCH)
+  int th_now = threshold;
   for (;;) {
     if (COUNT) pass_no++;
     TDT_ST1(STAT_LOOP_PASS, 1);
@@ -248,16 +278,19 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     {
       // Flat form: every lane evaluates the loop condition and the position (the values of lanes that are not traversing
       // are never used), so the step is ONE exec region instead of three nested ones.
-      const bool trav = state == ST_TRAVERSE;
+      const bool trav = __builtin_amdgcn_inverse_ballot_w64(k_trav);
+      const unsigned long long k_trav0 = k_trav;
       if (COUNT && trav) { lane_S++; cnt.trav_slots += slot64(); cnt.trav_active++; }
       const bool go = trav && (it < P.max_iter) && (t_stride < t_octree_max);      // else: OctreeHit returns false rc:449
-      const float adv = f_max(0.0001f * (inv_pow_depth + 0.1f), 0.000001f);
+      // rc:412 max(1e-4 (inv_pow_depth + 0.1), 1e-6): in the exact forms inv_pow_depth of a traversing lane is 2^-levels > 0, so the first
+      // operand is >= 1e-5 and the max returns it (lanes in other states carry other things in that register; their value is never used)
+      const float adv = POW2 ? 0.0001f * (inv_pow_depth + 0.1f) : f_max(0.0001f * (inv_pow_depth + 0.1f), 0.000001f);
       const float tt = t_stride + adv;
       const float wx = tt * r.dx + r.ox, wy = tt * r.dy + r.oy, wz = tt * r.dz + r.oz;
       // UNIT: scale and 1 / scale are exactly 1.0f (the reference's own scene, main.rs:457, and every scene here), and x * 1.0f is
       // x for every x — seven multiplications of the step that need not be issued (64^3 -1.6 %, 256^3 -1.2 %)
-      const float lx = UNIT ? (wx + -P.min_x) : (wx + -P.min_x) * P.inv_scale, ly = UNIT ? (wy + -P.min_y) : (wy + -P.min_y) * P.inv_scale,
-                  lz = UNIT ? (wz + -P.min_z) : (wz + -P.min_z) * P.inv_scale;
+      const float lx = UNIT ? (wx + -vmin_x) : (wx + -vmin_x) * P.inv_scale, ly = UNIT ? (wy + -vmin_y) : (wy + -vmin_y) * P.inv_scale,
+                  lz = UNIT ? (wz + -vmin_z) : (wz + -vmin_z) * P.inv_scale;
       bool in_box;
       if (POW2) {
         // rc:417 "fract(p) - p != vec3(0)": fract(p) - p is zero exactly for p in [0,1) (and -0).  As ONE unsigned compare:
@@ -283,7 +316,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
                                : tree_lookup<COUNT>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, cnt);
         TDT_MARK(traversal_b);
         lane_work += kCostStep + (127u - (__float_as_uint(inv_pow_depth) >> 23));   // + tree levels visited (inv_pow_depth = 2^-levels)
-        const float bx = (UNIT ? ugx : ugx * P.scale) + P.min_x, by = (UNIT ? ugy : ugy * P.scale) + P.min_y, bz = (UNIT ? ugz : ugz * P.scale) + P.min_z;
+        const float bx = (UNIT ? ugx : ugx * P.scale) + vmin_x, by = (UNIT ? ugy : ugy * P.scale) + vmin_y, bz = (UNIT ? ugz : ugz * P.scale) + vmin_z;
         const float cs0 = UNIT ? inv_pow_depth : P.scale * inv_pow_depth;
         // leaf: the exact cell (rc:427-428); empty: padded by -1e-5 / +2e-5 (rc:441-442)
         // (x + -0.0f is x, bit for bit, for every x: one select on the pad instead of one per coordinate)
@@ -306,6 +339,8 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
         }
       }
       state = (trav && !inside) ? ST_END : state;       // left the octree / ran out of iterations
+      k_trav &= __ballot(state == ST_TRAVERSE);          // (ONE compare of `state` per pass: who still traverses; whoever left has an event to be served)
+      k_event = ~k_trav & (k_event | k_trav0);
     }
 
     TDT_TICK(0);
@@ -321,21 +356,17 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     };
     if (state != ST_TRAVERSE && p_state == ST_TRAVERSE) k2_swap();      // the active context waits (or is done): the parked one takes the steps
     if (++k2_passes > (8u << 20)) break;                                 // (a proxy must not be able to hang the GPU)
-    const unsigned long long m_trav = __ballot(state == ST_TRAVERSE);
-    const unsigned long long m_event = __ballot(state > ST_TRAVERSE || p_state > ST_TRAVERSE);      // lanes with a context to serve
-    if (m_trav == 0ull && m_event == 0ull) break;
-#else
-    const unsigned long long m_trav = __ballot(state == ST_TRAVERSE);
-    const unsigned long long m_event = __ballot(state > ST_TRAVERSE);
-    if (m_trav == 0ull && m_event == 0ull) break;
+    k_trav = __ballot(state == ST_TRAVERSE);
+    k_event = __ballot(state > ST_TRAVERSE || p_state > ST_TRAVERSE);      // lanes with a context to serve
+    { const int n_alive = __popcll(k_trav | k_event); th_now = n_alive == 64 ? threshold : ((threshold * n_alive) >> 6) + 1; }
 #endif
+    const unsigned long long m_trav = k_trav, m_event = k_event;
+    if (m_trav == 0ull && m_event == 0ull) break;
     w_steps += (uint32_t)__popcll(m_trav);            // lanes that take the next traversal step
     // run the (long, material-divergent) event code only when enough lanes wait for it (a separate
     // threshold for scatter alone was measured: worse at every setting)
     // once the queue has run dry lanes retire (ST_DONE) and only latency is left to win: scale the threshold
     // with the lanes still alive so that the survivors do not wait for company that will never come
-    const int n_alive = __popcll(m_trav | m_event);
-    const int th_now = n_alive == 64 ? threshold : ((threshold * n_alive) >> 6) + 1;
     TDT_ST1(STAT_GATE_WAIT_LANES, __popcll(m_event));      // (every pass: lanes parked at the gate or about to be served)
     if ((int)__popcll(m_event) < th_now && m_trav != 0ull) { TDT_TICK(1); continue; }
     TDT_TICK(1);
@@ -356,7 +387,36 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       if (COUNT) { cnt.scatter_slots += slot64(); cnt.scatter_active++; }
       const MatRef mat = material_fetch(ms, hit_index);
       TDT_ST(STAT_LAMB_PASS, __ballot(mat.type == 0u)); TDT_ST(STAT_METAL_PASS, __ballot(mat.type == 1u)); TDT_ST(STAT_DIEL_PASS, __ballot(mat.type == 2u));
-#ifdef TDT_LAZY_ROOT
+#if defined(TDT_MEMCARRY)
+      float4 *const M = reinterpret_cast<float4 *>(P.carry) + pix * 4;
+      HitTmp k_leaf = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}, k_root = k_leaf;
+      if (owed.new_record()) {
+        cube_hit_record(r, t_stride, leaf_box_x, leaf_box_y, leaf_box_z, inv_pow_depth, k_leaf); if (COUNT) cnt.leaf_records++;
+        M[2] = make_float4(k_leaf.nx, k_leaf.ny, k_leaf.nz, k_leaf.px); M[3] = make_float4(k_leaf.py, k_leaf.pz, k_leaf.ff ? 1.f : 0.f, 0.f);
+      }
+      {
+        const bool need_root = !owed.leaf_site();                       // the hit was found by the first lookup: the ROOT call site's record (rc:426-437)
+        const bool root_mine = t_octree_max != inf;                     // this ray's own root test hit (else memory holds the ray whose test last did — possibly this one)
+        const bool stale_leaf = owed.leaf_site() && !owed.new_record(); // the leaf's slab test missed: what that call site produced last time
+        Ray rr = r; float rt = pc.root_t; bool none = false;
+        if (__builtin_expect(__ballot(stale_leaf || (need_root && !root_mine)) != 0ull, 0)) {
+          if (stale_leaf) {
+            const float4 c2 = ld_carry(M + 2), c3 = ld_carry(M + 3);
+            k_leaf = {c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z != 0.f};
+          }
+          if (need_root && !root_mine) {
+            const float4 c0 = ld_carry(M), c1 = ld_carry(M + 1);
+            rr = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y}; rt = c1.w;
+            none = c0.w == 0.f && c1.x == 0.f && c1.y == 0.f;
+          }
+        }
+        if (__ballot(need_root) != 0ull) {
+          if (need_root) { cube_hit_record(rr, rt, P.min_x, P.min_y, P.min_z, P.scale, k_root); if (none) k_root = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}; }
+        }
+      }
+      loop_count += 1;
+      const HitTmp &src = owed.leaf_site() ? k_leaf : k_root;
+#elif defined(TDT_LAZY_ROOT)
       // (experiment, not bit-exact in the stale-record cases: no record is carried — the leaf call site's is this hit's own, the root call
       // site's is recomputed from the ray and the root entry parameter when a hit needs it)
       HitTmp k_leaf = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}, k_root = k_leaf;
@@ -373,7 +433,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       h.px = src.px; h.py = src.py; h.pz = src.pz; h.nx = src.nx; h.ny = src.ny; h.nz = src.nz; h.ff = src.ff;
       h.index = hit_index;
       Ray nr; float tr, tg, tb;
-      const bool scattered = scatter<COUNT>(ms, r, h, mat, nr, tr, tg, tb, cnt);
+      const bool scattered = scatter<COUNT, !BRICK>(ms, r, h, mat, nr, tr, tg, tb, cnt);
       TDT_MARK(hit_epilogue);
       if (scattered) {
         ar = ar * tr; ag = ag * tg; ab = ab * tb;
@@ -405,7 +465,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
         float4 *dst = reinterpret_cast<float4 *>(P.image) + pix;
         if (P.accumulate) {
           *dst = make_float4(sr, sg, sb, 0.f);
-#ifndef TDT_LAZY_ROOT
+#if !defined(TDT_LAZY_ROOT) && !defined(TDT_NO_CARRY_IO) && !defined(TDT_MEMCARRY)      // (MEMCARRY: the records are in memory already; NO_CARRY_IO: experiment — what the 64 B per pixel of carry traffic between the launches of a two-phase frame cost; wrong pixels)
           if (P.carry && !P.carry_final) {           // (the last launch of a two-phase frame: nobody will read the records again)
             float4 *c = reinterpret_cast<float4 *>(P.carry) + pix * 4;
             c[0] = make_float4(pc.root.nx, pc.root.ny, pc.root.nz, pc.root.px);
@@ -482,11 +542,20 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
             if (inside) {                             // outside the covered image: ask again next time
               n_pixels++;
               sr = 0.f; sg = 0.f; sb = 0.f; s = P.spp_begin;
+#ifdef TDT_MEMCARRY
+              pc.root_t = 0.f;
+              {
+                float4 *const M = reinterpret_cast<float4 *>(P.carry) + pix * 4;
+                if (P.accumulate && P.spp_begin != 0 && P.carry_keep) pc.root_t = M[1].w;      // the records of the earlier passes stay where they are
+                else { const float4 z = make_float4(0.f, 0.f, 0.f, 0.f); M[0] = z; M[1] = z; M[2] = z; M[3] = z; }
+              }
+#else
               pc.root = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}; pc.leaf = pc.root; pc.root_t = 0.f;
+#endif
               if (P.accumulate && P.spp_begin != 0) {    // (a range that starts at sample 0 starts from nothing)
                 const float4 acc = *(reinterpret_cast<const float4 *>(P.image) + pix);
                 sr = acc.x; sg = acc.y; sb = acc.z;
-#ifndef TDT_LAZY_ROOT
+#if !defined(TDT_LAZY_ROOT) && !defined(TDT_NO_CARRY_IO) && !defined(TDT_MEMCARRY)
                 if (P.carry) {
                   const float4 *c = reinterpret_cast<const float4 *>(P.carry) + pix * 4;
                   const float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
@@ -542,7 +611,10 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
         const float t_exit = hw_min(hw_min(hw_min(mxx, inf), mxy), mxz);
         t_octree_max = inf;
         if (t_exit >= t_enter) {
-#ifndef TDT_LAZY_ROOT
+#if defined(TDT_MEMCARRY)
+          float4 *const M = reinterpret_cast<float4 *>(P.carry) + pix * 4;      // the ray and its entry parameter: what the root call site's record is made of
+          M[0] = make_float4(r.ox, r.oy, r.oz, r.dx); M[1] = make_float4(r.dy, r.dz, 0.f, t_enter);
+#elif !defined(TDT_LAZY_ROOT)
           cube_hit_record(r, t_enter, P.min_x, P.min_y, P.min_z, P.scale, pc.root);
 #endif
           pc.root_t = t_enter;
@@ -555,6 +627,8 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       }
     }
     TDT_TICK(6);
+    k_trav = __ballot(state == ST_TRAVERSE); k_event = __ballot(state > ST_TRAVERSE);
+    { const int n_alive = __popcll(k_trav | k_event); th_now = n_alive == 64 ? threshold : ((threshold * n_alive) >> 6) + 1; }
     TDT_MARK(loop_tail);
   }
   TDT_MARK(after_loop);
@@ -1332,6 +1406,23 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
   P.metal = (const uint32_t *)ctx->ssbo[TDT_SLOT_METAL]->dev; P.metal_dwords = dwords(ctx->ssbo[TDT_SLOT_METAL]);
   P.dielectric = (const uint32_t *)ctx->ssbo[TDT_SLOT_DIELECTRIC]->dev; P.dielectric_dwords = dwords(ctx->ssbo[TDT_SLOT_DIELECTRIC]);
   P.image = img->dev; P.carry = (float *)carry; P.carry_final = ctx->carry_final ? 1 : 0;
+#ifdef TDT_MEMCARRY
+  P.carry_keep = carry != nullptr ? 1 : 0;
+  if (!carry && (mode == 0 || mode == 1)) {            // the kernels keep the call sites' records in memory: a launch without a caller's carry uses the context's own block
+    const Cover k0 = cover_of(c, width, height);
+    const Tiles t0 = tiles_of(c, k0);
+    const size_t px = (size_t)img->w * (size_t)img->h, slots = (size_t)(t0.owned > 0 ? t0.owned : 0) * 1024;
+    const size_t need = (px > slots ? px : slots) * 16 * sizeof(float);
+    TDT_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->frame_carry_bytes < need) {
+      if (ctx->frame_carry) { TDT_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->frame_carry); }
+      ctx->frame_carry = nullptr; ctx->frame_carry_bytes = 0;
+      TDT_HIP(ctx, hipMalloc(&ctx->frame_carry, need));
+      ctx->frame_carry_bytes = need;
+    }
+    P.carry = (float *)ctx->frame_carry;
+  }
+#endif
   if (mode == 2) P.carry_final = ctx->use_done ? 1 : 0;      // resolve: skip the pixels the frame's miss pre-pass finished (only then: tdt_dispatch_resolve on its own resolves every pixel)
   Cover k = cover_of(c, width, height);
   Tiles t = tiles_of(c, k);

@@ -292,8 +292,15 @@ TDT_DEV void cube_slabs(const Ray &r, float ix, float iy, float iz, float cx, fl
   float ux = ((cx + size) + -r.ox) * ix, uy = ((cy + size) + -r.oy) * iy, uz = ((cz + size) + -r.oz) * iz;
   float mnx = hw_min(lx, ux), mny = hw_min(ly, uy), mnz = hw_min(lz, uz);
   float mxx = hw_max(lx, ux), mxy = hw_max(ly, uy), mxz = hw_max(lz, uz);
-  t_enter = hw_max(hw_max(hw_max(t_min, mnx), mny), mnz);
-  t_exit = hw_min(hw_min(hw_min(t_max, mxx), mxy), mxz);
+  // the chain through the instructions themselves: __builtin_fmaxf canonicalises operands the compiler cannot prove quiet (t_min, t_max
+  // are loop-carried: a v_max_f32 x, x each, half-rate instructions); every operand here comes out of fp32 arithmetic, which never yields a
+  // signalling NaN, and v_max / v_min return the other operand for a quiet NaN exactly as fmaxf / fminf do
+  float e1, e3, x1, x3;
+  asm("v_max_f32 %0, %1, %2" : "=v"(e1) : "v"(t_min), "v"(mnx));
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(e3) : "v"(e1), "v"(mny), "v"(mnz));
+  asm("v_min_f32 %0, %1, %2" : "=v"(x1) : "v"(t_max), "v"(mxx));
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(x3) : "v"(x1), "v"(mxy), "v"(mxz));
+  t_enter = e3; t_exit = x3;      // = hw_max(hw_max(hw_max(t_min, mnx), mny), mnz), hw_min(hw_min(hw_min(t_max, mxx), mxy), mxz)
 }
 
 // treeLookup rc:359-394: one dependent 8-byte Node load per level
@@ -788,7 +795,9 @@ TDT_DEV void unit_or_normalised(float nx, float ny, float nz, float &mx, float &
 }
 
 // switch (materials[hit.index].type) rc:278-291; returns false when the path ends
-template <bool COUNT>
+// SHARED_RAND: Rand(hit.point.xy) is the first draw of BOTH ScatterMetal (rc:488 via RandVec3) and ScatterDielectric (rc:513) — one evaluation
+// for the lanes of either kind (bench frame -1.2 %; the brick builds, at the edge of their register budget, lose 0.5 % to it and keep two)
+template <bool COUNT, bool SHARED_RAND = false>
 TDT_DEV bool scatter(const MatSource &ms, const Ray &r, const Hit &h, const MatRef &mat, Ray &out, float &ar, float &ag, float &ab, Counters &cnt) {
   const int32_t type = (int32_t)mat.type;
   // the second-level reads, all of them, before the switch (see MatSource); used at the end of the branches
@@ -799,11 +808,8 @@ TDT_DEV bool scatter(const MatSource &ms, const Ray &r, const Hit &h, const MatR
   float nx = h.nx, ny = h.ny, nz = h.nz;
   out.ox = h.px; out.oy = h.py; out.oz = h.pz;
   if (COUNT) { cnt.lambertian += (type == 0); cnt.metal += (type == 1); cnt.dielectric += (type == 2); cnt.unknown += ((uint32_t)type > 2u); }
-#ifdef TDT_SHARED_RAND2
-  // Rand(hit.point.xy) is the first draw of BOTH ScatterMetal (rc:488 via RandVec3) and ScatterDielectric (rc:513): one evaluation for the lanes of either kind
   float rnd_md = 0.0f;
-  if (type == 1 || type == 2) rnd_md = rand2(h.px, h.py);
-#endif
+  if (SHARED_RAND && (type == 1 || type == 2)) rnd_md = rand2(h.px, h.py);
   if (type == 0) {   // ScatterLambertian rc:470-482, constructFrisvad rc:453-468, SampleGGXVNDF rc:27-49
     TDT_MARK(lambert);
     float mx, my, mz; float rs;
@@ -868,11 +874,7 @@ TDT_DEV bool scatter(const MatSource &ms, const Ray &r, const Hit &h, const MatR
     float dt = ((mz * dz + my * dy) + mx * dx) * 2.0f;
     float rx = dx + -(dt * mx), ry = dy + -(dt * my), rz = dz + -(dt * mz);
     const float fuzz = m_fuzz;
-#ifdef TDT_SHARED_RAND2
-    float hx = -1.0f + 2.0f * rnd_md;
-#else
-    float hx = -1.0f + 2.0f * rand2(h.px, h.py);
-#endif
+    float hx = -1.0f + 2.0f * (SHARED_RAND ? rnd_md : rand2(h.px, h.py));
     float hy = -1.0f + 2.0f * rand2(h.px + hx, h.py + hx);
     float hz = -1.0f + 2.0f * rand2(h.px + hy, h.py + hy);
     bool same = -(hz * nz + hy * ny) < hx * nx;
@@ -893,11 +895,7 @@ TDT_DEV bool scatter(const MatSource &ms, const Ray &r, const Hit &h, const MatR
     bool cannot = 1.0f < ratio * sin_t;
     float q = schlick_q(ratio);
     float r0 = q * q;
-#ifdef TDT_SHARED_RAND2
-    float rnd = rnd_md;
-#else
-    float rnd = rand2(h.px, h.py);
-#endif
+    float rnd = SHARED_RAND ? rnd_md : rand2(h.px, h.py);
     float refl = pow_poly(1.0f + -cos_t, 5.0f) * (1.0f + -r0) + r0;
     float dn = (pz_ + py_) + px_;
     float ox_, oy_, oz_;
