@@ -251,6 +251,10 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   // node loads' latency, not issue slots, bounds a traversal pass and event passes come almost free.  (Round 2, after the
   // traversal step had become cheaper: 0.12 ... 0.35.)
   uint32_t w_steps = 0, w_rays = 0, lane_work = 0;
+#ifdef TDT_SLIM3
+  uint32_t w_steps_acc;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(w_steps_acc));
+#endif
   int threshold = P.event_threshold > 0 ? P.event_threshold : 24;
 
   // region timers of the instrumented build (s_memtime, wave-uniform): 0 traversal step, 1 gate, 2 hit + scatter, 3 end of path,
@@ -297,7 +301,13 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
         // the bit pattern of a float in [+0, 1) is below that of 1.0f; negative numbers carry the sign bit, NaN / inf / p >= 1
         // are larger; and p + 0.0f is p for every p except -0, which it turns into +0 (so -0 passes, as it does in the shader).
         // 3 adds + v_max3_u32 + 1 compare instead of 6 compares and 6 mask ANDs.
+#ifdef TDT_SLIM2
+        // (UNIT builds: the host also checked that no component of the corner is a zero — a sum x + y is -0 only when both terms are, so
+        // lx = wx + -min cannot be -0 and the three additions of +0 are not needed)
+        const uint32_t ux = __float_as_uint(UNIT ? lx : lx + 0.0f), uy = __float_as_uint(UNIT ? ly : ly + 0.0f), uz = __float_as_uint(UNIT ? lz : lz + 0.0f);
+#else
         const uint32_t ux = __float_as_uint(lx + 0.0f), uy = __float_as_uint(ly + 0.0f), uz = __float_as_uint(lz + 0.0f);
+#endif
         const uint32_t um = ux > uy ? ux : uy;
         in_box = (um > uz ? um : uz) < 0x3F800000u;
       } else {
@@ -315,28 +325,52 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
         const bool leaf = POW2 ? tree_lookup_pow2<COUNT, kMemoLevels, DEPTH, RESIDENT, SAFEV, FULL, BRICK, TABLE>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, memo, cnt)
                                : tree_lookup<COUNT>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, cnt);
         TDT_MARK(traversal_b);
+#ifndef TDT_SLIM2
         lane_work += kCostStep + (127u - (__float_as_uint(inv_pow_depth) >> 23));   // + tree levels visited (inv_pow_depth = 2^-levels)
+#endif
         const float bx = (UNIT ? ugx : ugx * P.scale) + vmin_x, by = (UNIT ? ugy : ugy * P.scale) + vmin_y, bz = (UNIT ? ugz : ugz * P.scale) + vmin_z;
         const float cs0 = UNIT ? inv_pow_depth : P.scale * inv_pow_depth;
         // leaf: the exact cell (rc:427-428); empty: padded by -1e-5 / +2e-5 (rc:441-442)
         // (x + -0.0f is x, bit for bit, for every x: one select on the pad instead of one per coordinate)
         const float pad = leaf ? -0.0f : -0.00001f;
+#ifdef TDT_SLIM2
+        // (the cell's corner and what it holds straight into the registers a hit carries to the event code: they mean nothing while a lane
+        // traverses, so every lane in the octree writes them — no copies in the leaf branch)
+        leaf_box_x = bx + pad; leaf_box_y = by + pad; leaf_box_z = bz + pad; hit_index = value;
+        const float cx = leaf_box_x, cy = leaf_box_y, cz = leaf_box_z;
+#else
         const float cx = bx + pad, cy = by + pad, cz = bz + pad;
+#endif
         const float cs = leaf ? cs0 : cs0 + 0.00002f;
         float t_enter, t_exit;
         cube_slabs(r, ix, iy, iz, cx, cy, cz, cs, t_stride, t_octree_max, t_enter, t_exit);
         const bool cube_ok = !(t_exit < t_enter);
+#ifdef TDT_SLIM4
+        // (the leaf / empty tail without a branch: selects on the vector unit instead of seven scalar instructions of exec bookkeeping)
+        t_stride = leaf ? t_enter : (cube_ok ? t_exit : t_octree_max);
+        inv_pow_depth = leaf ? cs : inv_pow_depth;
+        if constexpr (BRICK || DEPTH == 0) { if (leaf) owed.set(it > 0, cube_ok); }
+        else owed.bits = leaf ? (it > 0 ? (cube_ok ? 3u : 1u) : 0u) : owed.bits;
+        state = leaf ? ST_HIT : state;
+        it += leaf ? 0 : 1;
+#else
         if (leaf) {
           // CubeHit's record (rc:336-354) is deferred to the event code, where the lanes that hit
           // are batched: only a few lanes per step reach a leaf.  The traversal registers are
           // dead from here on, so they carry the cube.
+#ifdef TDT_SLIM2
+          inv_pow_depth = cs; t_stride = t_enter;
+          owed.set(it > 0, cube_ok);
+#else
           leaf_box_x = cx; leaf_box_y = cy; leaf_box_z = cz; inv_pow_depth = cs; t_stride = t_enter;
           owed.set(it > 0, cube_ok); hit_index = value;
+#endif
           state = ST_HIT;
         } else {
           t_stride = cube_ok ? t_exit : t_octree_max;
           it++;
         }
+#endif
       }
       state = (trav && !inside) ? ST_END : state;       // left the octree / ran out of iterations
       k_trav &= __ballot(state == ST_TRAVERSE);          // (ONE compare of `state` per pass: who still traverses; whoever left has an event to be served)
@@ -361,14 +395,28 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     { const int n_alive = __popcll(k_trav | k_event); th_now = n_alive == 64 ? threshold : ((threshold * n_alive) >> 6) + 1; }
 #endif
     const unsigned long long m_trav = k_trav, m_event = k_event;
+#ifndef TDT_SLIM3
     if (m_trav == 0ull && m_event == 0ull) break;
+#endif
+#ifdef TDT_SLIM3
+    // lanes that take the next traversal step — summed on the scalar unit (asm: the compiler folds a C++ accumulator back into w_steps, which
+    // the vector unit's threshold formula reads, and adds to it with a half-rate VALU instruction every pass); added to w_steps once per event pass
+    { const uint32_t n_ = (uint32_t)__popcll(m_trav); asm volatile("s_add_u32 %0, %0, %1" : "+s"(w_steps_acc) : "s"(n_) : "scc"); }
+#else
     w_steps += (uint32_t)__popcll(m_trav);            // lanes that take the next traversal step
+#endif
     // run the (long, material-divergent) event code only when enough lanes wait for it (a separate
     // threshold for scatter alone was measured: worse at every setting)
     // once the queue has run dry lanes retire (ST_DONE) and only latency is left to win: scale the threshold
     // with the lanes still alive so that the survivors do not wait for company that will never come
     TDT_ST1(STAT_GATE_WAIT_LANES, __popcll(m_event));      // (every pass: lanes parked at the gate or about to be served)
+#ifdef TDT_SLIM3
+    // (the gate on the scalar unit alone: th_now comes out of the event pass as a scalar — one v_readfirstlane per EVENT pass — and "nobody
+    // traverses" is a threshold of zero; the loop's exit test sits behind the event code, the only place a lane can retire)
+    if ((int)__popcll(m_event) < (m_trav != 0ull ? th_now : 0)) { TDT_TICK(1); continue; }
+#else
     if ((int)__popcll(m_event) < th_now && m_trav != 0ull) { TDT_TICK(1); continue; }
+#endif
     TDT_TICK(1);
     TDT_ST(STAT_EVENT_PASS, m_event); TDT_ST(STAT_HIT_PASS, __ballot(state == ST_HIT));
 #ifdef TDT_STATS
@@ -381,7 +429,15 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     TDT_MARK(hit_prologue);
     if (COUNT) evpass_no++;
     if (COUNT) { cnt.event_slots += slot64(); cnt.event_active += (state > ST_TRAVERSE); }
+#ifdef TDT_SLIM2
+    // a pixel's cost for the hand-out order (a schedule: no pixel depends on it): 64 per path event + kCostRayStep per traversal step of the
+    // ray that ends here — `it` counted them (the step that finds a leaf does not advance it: + 1) — added once per ray, in the event pass,
+    // instead of three instructions in every traversal step.  (The tree levels a step visited used to be part of it; with one table or
+    // brick read per step whatever the depth they no longer say what a step costs.)
+    lane_work += (state == ST_HIT || state == ST_END) ? kCostEvent + kCostRayStep * ((uint32_t)it + 1u) : ((state > ST_TRAVERSE) ? kCostEvent : 0u);
+#else
     lane_work += (state > ST_TRAVERSE) ? kCostEvent : 0u;
+#endif
     if (COUNT) lane_E += (state > ST_TRAVERSE) ? 1u : 0u;
     if (state == ST_HIT) {                            // RayColor loop body rc:272-295
       if (COUNT) { cnt.scatter_slots += slot64(); cnt.scatter_active++; }
@@ -420,7 +476,12 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       // (experiment, not bit-exact in the stale-record cases: no record is carried — the leaf call site's is this hit's own, the root call
       // site's is recomputed from the ray and the root entry parameter when a hit needs it)
       HitTmp k_leaf = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}, k_root = k_leaf;
+#if TDT_LAZY_ROOT == 2
+      if (owed.new_record()) cube_hit_record(r, t_stride, leaf_box_x, leaf_box_y, leaf_box_z, inv_pow_depth, pc.leaf);
+      k_leaf = pc.leaf;
+#else
       if (owed.new_record()) cube_hit_record(r, t_stride, leaf_box_x, leaf_box_y, leaf_box_z, inv_pow_depth, k_leaf);
+#endif
       if (__ballot(!owed.leaf_site()) != 0ull) { if (!owed.leaf_site()) cube_hit_record(r, pc.root_t, P.min_x, P.min_y, P.min_z, P.scale, k_root); }
       loop_count += 1;
       const HitTmp &src = owed.leaf_site() ? k_leaf : k_root;
@@ -584,6 +645,9 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       state = ST_NEWRAY;
     }
     TDT_MARK(threshold);
+#ifdef TDT_SLIM3
+    w_steps += w_steps_acc; asm volatile("s_mov_b32 %0, 0" : "=s"(w_steps_acc));
+#endif
     w_rays += (uint32_t)__popcll(__ballot(state == ST_NEWRAY));
     if (P.event_threshold <= 0) {
       if (w_rays > kEventWindow) { w_steps >>= 1; w_rays >>= 1; }   // sliding window: the mix of pixels a wave sees changes over a frame
@@ -628,7 +692,13 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     }
     TDT_TICK(6);
     k_trav = __ballot(state == ST_TRAVERSE); k_event = __ballot(state > ST_TRAVERSE);
+#ifdef TDT_SLIM3
+    if (k_trav == 0ull && k_event == 0ull) break;
+    { const int n_alive = __popcll(k_trav | k_event); const int th_s = __builtin_amdgcn_readfirstlane(threshold);
+      th_now = n_alive == 64 ? th_s : ((th_s * n_alive) >> 6) + 1; }
+#else
     { const int n_alive = __popcll(k_trav | k_event); th_now = n_alive == 64 ? threshold : ((threshold * n_alive) >> 6) + 1; }
+#endif
     TDT_MARK(loop_tail);
   }
   TDT_MARK(after_loop);
@@ -1715,7 +1785,11 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
       // UNIT builds do not multiply by a scale of exactly 1.0f (x * 1.0f is x).  The probe launch of a two-phase frame runs the build
       // that multiplies — the same bits, and the short launch then has a row of its own in profiler statistics instead of halving the
       // average of the launches that do the work
+#ifdef TDT_SLIM2
+      const bool unit = P.scale == 1.0f && P.inv_scale == 1.0f && P.min_x != 0.0f && P.min_y != 0.0f && P.min_z != 0.0f && !ctx->probe_launch;      // (a zero corner component: see the in-octree test)
+#else
       const bool unit = P.scale == 1.0f && P.inv_scale == 1.0f && !ctx->probe_launch;
+#endif
       const int form = pow2 ? tdt::FORM_POW2 : tdt::FORM_TABLE;
       TraceFn fn = nullptr;
       if (brick) fn = find_variant(form, P.max_depth, false, false, true, unit);

@@ -482,7 +482,7 @@ TDT_DEV void build_top_grid(const uint16_t *lds, uint32_t lds_nodes, int depth, 
 
 // a pixel's cost for the hand-out order of the next dispatch (tdt_rt.hip, "Cost-feedback scheduling"):
 // tree levels visited + kCostStep per traversal step + kCostEvent per path event (measured plateau 24..128)
-constexpr uint32_t kCostStep = 3, kCostEvent = 64;
+constexpr uint32_t kCostStep = 3, kCostEvent = 64, kCostRayStep = 7;      // (kCostRayStep: per step when the levels are not counted — 3 + the ~4 levels a step used to visit)
 constexpr uint32_t kEventWindow = 1024;   // rays after which the adaptive event threshold's running counts are halved
 constexpr int kMemoLevels = 9;
 // levels of the LDS jump table: 4 for trees inside the LDS table, 5 for the others (see Grid<GL>) — except FORM_TABLE trees outside
