@@ -142,7 +142,7 @@ def quoted(path, key):
 
 def quoted_valu(wkey):
     """(SQ-counter summary of the workload's dominant launch, the file it came from): the newest round that has one."""
-    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json"):
+    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"):
         v = quoted(name, wkey)
         if v:
             return v, "profiles/" + name

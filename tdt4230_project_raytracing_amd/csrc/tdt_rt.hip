@@ -61,22 +61,6 @@ TDT_DEV uint32_t wave_sum(uint32_t v) {
   return v;
 }
 
-#ifdef TDT_MEMCARRY
-// The call sites' carried hit records (see Carry) live in MEMORY, 64 B per pixel, not in 15 registers per lane: what a call site last
-// produced is read back only when a hit needs a record its own ray did not write (a slab test that missed: rare), so the registers were
-// held for the whole frame for the sake of a path taken by a handful of rays.  Layout of a pixel's block (float4 x 4):
-//   [0] = (o.x, o.y, o.z, d.x), [1] = (d.y, d.z, -, t) : the last ray whose ROOT slab test hit and its entry parameter — the root call site's
-//         record is a pure function of them (cube_hit_record on the root cube), recomputed when a hit at the first lookup needs it;
-//         d = 0 (no normalised direction is): no such ray yet, the record is the zeros main() starts from.  [1].w doubles as root_t.
-//   [2], [3] = the leaf call site's last record, as computed (n, p, front_face).
-// Stores are fire-and-forget (the block stays in L2 while its pixel is traced); the rare read-back waits for the wave's own stores and
-// bypasses the L1.
-TDT_DEV float4 ld_carry(const float4 *p) {
-  float4 v;
-  asm volatile("s_waitcnt vmcnt(0)\n\tglobal_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-#endif
 
 // Lane states of the flattened path tracer.  The reference's loop nest
 //   for sample { while bounce { for traversal-step { for level } } }        (rc:238,271,410,372)
@@ -129,6 +113,14 @@ TDT_DEV void stat_add(uint32_t *row, int i, unsigned long long mask) {      // m
 template <bool COUNT, int FORM, int DEPTH = 0, bool RESIDENT = false, bool SAFEV = false, bool FULL = false, bool UNIT = false, bool BRICK = false>
 __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   constexpr bool POW2 = FORM != FORM_LITERAL;        // the exact forms (integer digits, one-compare box test)
+  // round 4's second batch of step slimming (see the uses): the scene-specialised builds; the general kernel, with its nine-level node
+  // memo, sits at the register cap and keeps the plain forms
+  constexpr bool kSlim2 = DEPTH > 0;
+#ifdef TDT_BRICK_RAND2
+  constexpr bool kSharedRand = true;
+#else
+  constexpr bool kSharedRand = !BRICK;                // (scatter<>: one Rand(hit.xy) for metal and dielectric lanes)
+#endif
   __shared__ __attribute__((aligned(16))) uint16_t s_nodes[(BRICK ? kBrickLdsCells : kLdsCells) * 8 + 8];   // + the sentinel slot (BRICK: the host stages no more than fit)
   for (uint32_t i = threadIdx.x * 8u; i < P.lds_nodes; i += (uint32_t)TDT_BLOCK * 8u)      // one cell (8 x u16) per lane and trip
     *reinterpret_cast<uint4 *>(&s_nodes[i]) = *reinterpret_cast<const uint4 *>(&P.packed[i]);
@@ -189,9 +181,13 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   if (COUNT && (threadIdx.x & 63) == 0) atomicCAS(&P.counters[23], 0ull, wave_t0);   // time base of the pixel log   // 100 MHz, same on every XCD
   Counters cnt = {};
   uint32_t n_pixels = 0;
-  NodeMemo<kMemoLevels> memo;
+  // node-memo levels (2 VGPRs each): the brick builds' level walk is the fallback of the few per cent of their steps that have a lane in a
+  // band — three levels' worth of memo instead of nine pays for the octree corner in VGPRs and the hit flags in a VGPR there too
+  // (4K/256^3 -1.9 %, 1080p/512^3 -3.3 %; one or two levels: -1.0 / -2.9 %)
+  constexpr int kMemo = BRICK ? kBrickMemoLevels : kMemoLevels;
+  NodeMemo<kMemo> memo;
 #pragma unroll
-  for (int l = 0; l < kMemoLevels; l++) { memo.key[l] = 0x3FFFFFFFu; memo.val[l] = 0u; }
+  for (int l = 0; l < kMemo; l++) { memo.key[l] = 0x3FFFFFFFu; memo.val[l] = 0u; }
 
   int state = ST_FETCH;
   int x = 0, y = 0; size_t pix = 0;
@@ -208,39 +204,13 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   // what the hit found by the traversal step still owes the event code: bit 0 = the record is the leaf call site's (it > 0), bit 1 = that
   // call site writes a new record (its slab test hit).  As two bools the compiler keeps them as lane masks in scalar register pairs and
   // updates those with a dozen s_and / s_andn2 / s_or per pass; as an integer in a VGPR the pass is 16 scalar instructions shorter — which
-  // is worth 0.8 % where registers are to spare (the whole-depth-table and LDS-resident builds) and costs 0.5-3 % in the brick builds,
-  // which sit at 124-126 of 128 VGPRs: those keep the masks (measured both ways on configs 2 / 3 / 5)
-#ifdef TDT_K2_PROXY
-  HitOwed<false> owed;
-#else
-  HitOwed<BRICK || DEPTH == 0> owed;      // (the general kernel, with its nine-level memo, sits at the register cap like the brick builds)
-#endif
+  // is worth 0.8 % where registers are to spare (round 3: not in the brick builds; round 4 freed theirs by shortening the node memo)
+  HitOwed<DEPTH == 0> owed;      // (as lane masks in the general kernel, which sits at the register cap)
   uint32_t hit_index = 0;
-#ifdef TDT_K2_PROXY
-  float &leaf_box_x = ix, &leaf_box_y = iy, &leaf_box_z = iz;
-#else
   float leaf_box_x = 0.f, leaf_box_y = 0.f, leaf_box_z = 0.f;
-#endif
   Carry pc;
   pc.root = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}; pc.leaf = pc.root; pc.root_t = 0.f;
   const int s_end = P.spp_begin + P.spp_count;
-#if defined(TDT_K2_PROXY) && !defined(TDT_LAZY_ROOT)
-#define TDT_LAZY_ROOT 1
-#endif
-#ifdef TDT_K2_PROXY
-  // SPEED PROXY, NOT A RENDERER (tools/k2_proxy.sh; never the product library): a second path context per lane.  While a lane's active
-  // context waits at the event gate its parked one takes the traversal steps; an event pass serves one waiting context per lane.  Only
-  // the per-RAY state is doubled (and exchanged, v_swap_b32 under the mask of the lanes that switch); everything per PIXEL (sums,
-  // attenuation, sample counter, the pixel itself) is shared by the two contexts, so the image is garbage — but the passes, the lanes in
-  // them and the instructions are those of a two-context kernel whose per-pixel state lives outside the registers, i.e. an upper bound
-  // on what such a kernel could gain (measured before building it).
-  Ray p_r = {0.f, 0.f, 0.f, 0.f, 0.f, 1.f};
-  float p_ix = 0.f, p_iy = 0.f, p_iz = 0.f, p_t_stride = 0.f, p_t_max = 0.f, p_ipd = 0.5f, p_root_t = 0.f;
-  int p_it = 0, p_state = ST_PRIMARY, p_loop = 0;
-  uint32_t p_hit_index = 0, p_owed = 0, k2_passes = 0;
-
-#define TDT_K2_SWAP(a, b) asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b))
-#endif
 
   // adaptive event threshold (wave-uniform).  Model: a traversal pass costs C_t issue slots, an event pass C_e
   // whatever the number of lanes it serves; with threshold T about T/2 lanes idle through the traversal
@@ -261,11 +231,11 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   // 4 pixel fetch, 5 primary ray + threshold, 6 new-ray prologue -> counters[24..30]
   unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
 #define TDT_TICK(i) do { if (COUNT) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tacc[i] += n_ - tlast; tlast = n_; } } while (0)
-  // The octree's minimum corner in VGPRs (builds with registers to spare): a VALU instruction with an SGPR operand issues at half rate on
+  // The octree's minimum corner in VGPRs (the scene-specialised builds): a VALU instruction with an SGPR operand issues at half rate on
   // gfx950 (tools/micro/pipe_model.hip: v_add_f32 with an SGPR source 4.2 cycles, with VGPR sources 2.7), and the traversal step reads
   // these three twice each.  (asm: the compiler would fold a plain copy back into the scalar operand.)
   float vmin_x, vmin_y, vmin_z;
-  if (BRICK || DEPTH == 0) { vmin_x = P.min_x; vmin_y = P.min_y; vmin_z = P.min_z; }      // (the brick builds and the general kernel have no register to spare)
+  if (DEPTH == 0) { vmin_x = P.min_x; vmin_y = P.min_y; vmin_z = P.min_z; }      // (the general kernel has no register to spare)
   else asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=v"(vmin_x), "=v"(vmin_y), "=v"(vmin_z) : "s"(P.min_x), "s"(P.min_y), "s"(P.min_z));
   // The lanes in ST_TRAVERSE and in an event state as wave masks, carried from pass to pass: a traversal step only moves lanes out of
   // the first set into the second, so the masks after the step are mask algebra on the step's own conditions — no compare of `state`
@@ -301,13 +271,10 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
         // the bit pattern of a float in [+0, 1) is below that of 1.0f; negative numbers carry the sign bit, NaN / inf / p >= 1
         // are larger; and p + 0.0f is p for every p except -0, which it turns into +0 (so -0 passes, as it does in the shader).
         // 3 adds + v_max3_u32 + 1 compare instead of 6 compares and 6 mask ANDs.
-#ifdef TDT_SLIM2
         // (UNIT builds: the host also checked that no component of the corner is a zero — a sum x + y is -0 only when both terms are, so
         // lx = wx + -min cannot be -0 and the three additions of +0 are not needed)
-        const uint32_t ux = __float_as_uint(UNIT ? lx : lx + 0.0f), uy = __float_as_uint(UNIT ? ly : ly + 0.0f), uz = __float_as_uint(UNIT ? lz : lz + 0.0f);
-#else
-        const uint32_t ux = __float_as_uint(lx + 0.0f), uy = __float_as_uint(ly + 0.0f), uz = __float_as_uint(lz + 0.0f);
-#endif
+        constexpr bool kNoNegZero = UNIT && kSlim2;
+        const uint32_t ux = __float_as_uint(kNoNegZero ? lx : lx + 0.0f), uy = __float_as_uint(kNoNegZero ? ly : ly + 0.0f), uz = __float_as_uint(kNoNegZero ? lz : lz + 0.0f);
         const uint32_t um = ux > uy ? ux : uy;
         in_box = (um > uz ? um : uz) < 0x3F800000u;
       } else {
@@ -322,25 +289,19 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       if (inside) {
         float ugx, ugy, ugz; uint32_t value;
         if (COUNT) cnt.iterations++;
-        const bool leaf = POW2 ? tree_lookup_pow2<COUNT, kMemoLevels, DEPTH, RESIDENT, SAFEV, FULL, BRICK, TABLE>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, memo, cnt)
+        const bool leaf = POW2 ? tree_lookup_pow2<COUNT, kMemo, DEPTH, RESIDENT, SAFEV, FULL, BRICK, TABLE>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, memo, cnt)
                                : tree_lookup<COUNT>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, cnt);
         TDT_MARK(traversal_b);
-#ifndef TDT_SLIM2
-        lane_work += kCostStep + (127u - (__float_as_uint(inv_pow_depth) >> 23));   // + tree levels visited (inv_pow_depth = 2^-levels)
-#endif
+        if (!kSlim2) lane_work += kCostStep + (127u - (__float_as_uint(inv_pow_depth) >> 23));   // + tree levels visited (inv_pow_depth = 2^-levels)
         const float bx = (UNIT ? ugx : ugx * P.scale) + vmin_x, by = (UNIT ? ugy : ugy * P.scale) + vmin_y, bz = (UNIT ? ugz : ugz * P.scale) + vmin_z;
         const float cs0 = UNIT ? inv_pow_depth : P.scale * inv_pow_depth;
         // leaf: the exact cell (rc:427-428); empty: padded by -1e-5 / +2e-5 (rc:441-442)
         // (x + -0.0f is x, bit for bit, for every x: one select on the pad instead of one per coordinate)
         const float pad = leaf ? -0.0f : -0.00001f;
-#ifdef TDT_SLIM2
-        // (the cell's corner and what it holds straight into the registers a hit carries to the event code: they mean nothing while a lane
-        // traverses, so every lane in the octree writes them — no copies in the leaf branch)
-        leaf_box_x = bx + pad; leaf_box_y = by + pad; leaf_box_z = bz + pad; hit_index = value;
-        const float cx = leaf_box_x, cy = leaf_box_y, cz = leaf_box_z;
-#else
-        const float cx = bx + pad, cy = by + pad, cz = bz + pad;
-#endif
+        // (kSlim2: the cell's corner and what it holds straight into the registers a hit carries to the event code: they mean nothing while a
+        // lane traverses, so every lane in the octree writes them — no copies in the leaf branch)
+        if (kSlim2) { leaf_box_x = bx + pad; leaf_box_y = by + pad; leaf_box_z = bz + pad; hit_index = value; }
+        const float cx = kSlim2 ? leaf_box_x : bx + pad, cy = kSlim2 ? leaf_box_y : by + pad, cz = kSlim2 ? leaf_box_z : bz + pad;
         const float cs = leaf ? cs0 : cs0 + 0.00002f;
         float t_enter, t_exit;
         cube_slabs(r, ix, iy, iz, cx, cy, cz, cs, t_stride, t_octree_max, t_enter, t_exit);
@@ -358,13 +319,9 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
           // CubeHit's record (rc:336-354) is deferred to the event code, where the lanes that hit
           // are batched: only a few lanes per step reach a leaf.  The traversal registers are
           // dead from here on, so they carry the cube.
-#ifdef TDT_SLIM2
+          if (!kSlim2) { leaf_box_x = cx; leaf_box_y = cy; leaf_box_z = cz; hit_index = value; }
           inv_pow_depth = cs; t_stride = t_enter;
           owed.set(it > 0, cube_ok);
-#else
-          leaf_box_x = cx; leaf_box_y = cy; leaf_box_z = cz; inv_pow_depth = cs; t_stride = t_enter;
-          owed.set(it > 0, cube_ok); hit_index = value;
-#endif
           state = ST_HIT;
         } else {
           t_stride = cube_ok ? t_exit : t_octree_max;
@@ -373,27 +330,15 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
 #endif
       }
       state = (trav && !inside) ? ST_END : state;       // left the octree / ran out of iterations
-      k_trav &= __ballot(state == ST_TRAVERSE);          // (ONE compare of `state` per pass: who still traverses; whoever left has an event to be served)
+      // (ONE compare of `state` per pass: who still traverses; whoever left has an event to be served.  A ballot of the step's own conditions
+      //  — inside && !leaf — would need none, but the compiler lowers the ballot of a boolean that is not a compare to v_cndmask + v_cmp)
+      k_trav &= __ballot(state == ST_TRAVERSE);
       k_event = ~k_trav & (k_event | k_trav0);
     }
 
     TDT_TICK(0);
     // ------------------------------------------------------------ path events
     TDT_MARK(gate);
-#ifdef TDT_K2_PROXY
-    auto k2_swap = [&]() {      // (executed under the exec mask of the lanes that switch contexts)
-      TDT_K2_SWAP(r.ox, p_r.ox); TDT_K2_SWAP(r.oy, p_r.oy); TDT_K2_SWAP(r.oz, p_r.oz); TDT_K2_SWAP(r.dx, p_r.dx); TDT_K2_SWAP(r.dy, p_r.dy); TDT_K2_SWAP(r.dz, p_r.dz);
-      TDT_K2_SWAP(ix, p_ix); TDT_K2_SWAP(iy, p_iy); TDT_K2_SWAP(iz, p_iz); TDT_K2_SWAP(t_stride, p_t_stride); TDT_K2_SWAP(t_octree_max, p_t_max);
-      TDT_K2_SWAP(inv_pow_depth, p_ipd); TDT_K2_SWAP(it, p_it); TDT_K2_SWAP(state, p_state); TDT_K2_SWAP(loop_count, p_loop); TDT_K2_SWAP(hit_index, p_hit_index);
-      TDT_K2_SWAP(owed.bits, p_owed); TDT_K2_SWAP(pc.root_t, p_root_t);
-      // (the leaf's box lives in ix / iy / iz, dead between the leaf and the next ray: see leaf_box_x)
-    };
-    if (state != ST_TRAVERSE && p_state == ST_TRAVERSE) k2_swap();      // the active context waits (or is done): the parked one takes the steps
-    if (++k2_passes > (8u << 20)) break;                                 // (a proxy must not be able to hang the GPU)
-    k_trav = __ballot(state == ST_TRAVERSE);
-    k_event = __ballot(state > ST_TRAVERSE || p_state > ST_TRAVERSE);      // lanes with a context to serve
-    { const int n_alive = __popcll(k_trav | k_event); th_now = n_alive == 64 ? threshold : ((threshold * n_alive) >> 6) + 1; }
-#endif
     const unsigned long long m_trav = k_trav, m_event = k_event;
 #ifndef TDT_SLIM3
     if (m_trav == 0ull && m_event == 0ull) break;
@@ -423,78 +368,28 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     TDT_ST1(STAT_DRAINED_EVENT_PASS, stat_drained ? 1 : 0);
 #endif
 
-#ifdef TDT_K2_PROXY
-    if (state <= ST_TRAVERSE && p_state > ST_TRAVERSE) k2_swap();        // serve the parked context of lanes whose active one needs nothing
-#endif
     TDT_MARK(hit_prologue);
     if (COUNT) evpass_no++;
     if (COUNT) { cnt.event_slots += slot64(); cnt.event_active += (state > ST_TRAVERSE); }
-#ifdef TDT_SLIM2
-    // a pixel's cost for the hand-out order (a schedule: no pixel depends on it): 64 per path event + kCostRayStep per traversal step of the
-    // ray that ends here — `it` counted them (the step that finds a leaf does not advance it: + 1) — added once per ray, in the event pass,
-    // instead of three instructions in every traversal step.  (The tree levels a step visited used to be part of it; with one table or
+    // a pixel's cost for the hand-out order (a schedule: no pixel depends on it): 64 per path event + (kSlim2) kCostRayStep per traversal step
+    // of the ray that ends here — `it` counted them (the step that finds a leaf does not advance it: + 1) — added once per ray, in the event
+    // pass, instead of three instructions in every traversal step.  (The tree levels a step visited used to be part of it; with one table or
     // brick read per step whatever the depth they no longer say what a step costs.)
-    lane_work += (state == ST_HIT || state == ST_END) ? kCostEvent + kCostRayStep * ((uint32_t)it + 1u) : ((state > ST_TRAVERSE) ? kCostEvent : 0u);
-#else
-    lane_work += (state > ST_TRAVERSE) ? kCostEvent : 0u;
-#endif
+    if (kSlim2) lane_work += (state == ST_HIT || state == ST_END) ? kCostEvent + kCostRayStep * ((uint32_t)it + 1u) : ((state > ST_TRAVERSE) ? kCostEvent : 0u);
+    else lane_work += (state > ST_TRAVERSE) ? kCostEvent : 0u;
     if (COUNT) lane_E += (state > ST_TRAVERSE) ? 1u : 0u;
     if (state == ST_HIT) {                            // RayColor loop body rc:272-295
       if (COUNT) { cnt.scatter_slots += slot64(); cnt.scatter_active++; }
       const MatRef mat = material_fetch(ms, hit_index);
       TDT_ST(STAT_LAMB_PASS, __ballot(mat.type == 0u)); TDT_ST(STAT_METAL_PASS, __ballot(mat.type == 1u)); TDT_ST(STAT_DIEL_PASS, __ballot(mat.type == 2u));
-#if defined(TDT_MEMCARRY)
-      float4 *const M = reinterpret_cast<float4 *>(P.carry) + pix * 4;
-      HitTmp k_leaf = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}, k_root = k_leaf;
-      if (owed.new_record()) {
-        cube_hit_record(r, t_stride, leaf_box_x, leaf_box_y, leaf_box_z, inv_pow_depth, k_leaf); if (COUNT) cnt.leaf_records++;
-        M[2] = make_float4(k_leaf.nx, k_leaf.ny, k_leaf.nz, k_leaf.px); M[3] = make_float4(k_leaf.py, k_leaf.pz, k_leaf.ff ? 1.f : 0.f, 0.f);
-      }
-      {
-        const bool need_root = !owed.leaf_site();                       // the hit was found by the first lookup: the ROOT call site's record (rc:426-437)
-        const bool root_mine = t_octree_max != inf;                     // this ray's own root test hit (else memory holds the ray whose test last did — possibly this one)
-        const bool stale_leaf = owed.leaf_site() && !owed.new_record(); // the leaf's slab test missed: what that call site produced last time
-        Ray rr = r; float rt = pc.root_t; bool none = false;
-        if (__builtin_expect(__ballot(stale_leaf || (need_root && !root_mine)) != 0ull, 0)) {
-          if (stale_leaf) {
-            const float4 c2 = ld_carry(M + 2), c3 = ld_carry(M + 3);
-            k_leaf = {c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z != 0.f};
-          }
-          if (need_root && !root_mine) {
-            const float4 c0 = ld_carry(M), c1 = ld_carry(M + 1);
-            rr = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y}; rt = c1.w;
-            none = c0.w == 0.f && c1.x == 0.f && c1.y == 0.f;
-          }
-        }
-        if (__ballot(need_root) != 0ull) {
-          if (need_root) { cube_hit_record(rr, rt, P.min_x, P.min_y, P.min_z, P.scale, k_root); if (none) k_root = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}; }
-        }
-      }
-      loop_count += 1;
-      const HitTmp &src = owed.leaf_site() ? k_leaf : k_root;
-#elif defined(TDT_LAZY_ROOT)
-      // (experiment, not bit-exact in the stale-record cases: no record is carried — the leaf call site's is this hit's own, the root call
-      // site's is recomputed from the ray and the root entry parameter when a hit needs it)
-      HitTmp k_leaf = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}, k_root = k_leaf;
-#if TDT_LAZY_ROOT == 2
-      if (owed.new_record()) cube_hit_record(r, t_stride, leaf_box_x, leaf_box_y, leaf_box_z, inv_pow_depth, pc.leaf);
-      k_leaf = pc.leaf;
-#else
-      if (owed.new_record()) cube_hit_record(r, t_stride, leaf_box_x, leaf_box_y, leaf_box_z, inv_pow_depth, k_leaf);
-#endif
-      if (__ballot(!owed.leaf_site()) != 0ull) { if (!owed.leaf_site()) cube_hit_record(r, pc.root_t, P.min_x, P.min_y, P.min_z, P.scale, k_root); }
-      loop_count += 1;
-      const HitTmp &src = owed.leaf_site() ? k_leaf : k_root;
-#else
       if (owed.new_record()) { cube_hit_record(r, t_stride, leaf_box_x, leaf_box_y, leaf_box_z, inv_pow_depth, pc.leaf); if (COUNT) cnt.leaf_records++; }
       loop_count += 1;
       const HitTmp &src = owed.leaf_site() ? pc.leaf : pc.root;
-#endif
       Hit h;
       h.px = src.px; h.py = src.py; h.pz = src.pz; h.nx = src.nx; h.ny = src.ny; h.nz = src.nz; h.ff = src.ff;
       h.index = hit_index;
       Ray nr; float tr, tg, tb;
-      const bool scattered = scatter<COUNT, !BRICK>(ms, r, h, mat, nr, tr, tg, tb, cnt);
+      const bool scattered = scatter<COUNT, kSharedRand>(ms, r, h, mat, nr, tr, tg, tb, cnt);
       TDT_MARK(hit_epilogue);
       if (scattered) {
         ar = ar * tr; ag = ag * tg; ab = ab * tb;
@@ -526,7 +421,6 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
         float4 *dst = reinterpret_cast<float4 *>(P.image) + pix;
         if (P.accumulate) {
           *dst = make_float4(sr, sg, sb, 0.f);
-#if !defined(TDT_LAZY_ROOT) && !defined(TDT_NO_CARRY_IO) && !defined(TDT_MEMCARRY)      // (MEMCARRY: the records are in memory already; NO_CARRY_IO: experiment — what the 64 B per pixel of carry traffic between the launches of a two-phase frame cost; wrong pixels)
           if (P.carry && !P.carry_final) {           // (the last launch of a two-phase frame: nobody will read the records again)
             float4 *c = reinterpret_cast<float4 *>(P.carry) + pix * 4;
             c[0] = make_float4(pc.root.nx, pc.root.ny, pc.root.nz, pc.root.px);
@@ -534,7 +428,6 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
             c[2] = make_float4(pc.leaf.nx, pc.leaf.ny, pc.leaf.nz, pc.leaf.px);
             c[3] = make_float4(pc.leaf.py, pc.leaf.pz, pc.leaf.ff ? 1.f : 0.f, 0.f);
           }
-#endif
         } else {
           const float n = (float)P.samples_per_pixel;   // rc:249-251
           float4 o;
@@ -603,27 +496,16 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
             if (inside) {                             // outside the covered image: ask again next time
               n_pixels++;
               sr = 0.f; sg = 0.f; sb = 0.f; s = P.spp_begin;
-#ifdef TDT_MEMCARRY
-              pc.root_t = 0.f;
-              {
-                float4 *const M = reinterpret_cast<float4 *>(P.carry) + pix * 4;
-                if (P.accumulate && P.spp_begin != 0 && P.carry_keep) pc.root_t = M[1].w;      // the records of the earlier passes stay where they are
-                else { const float4 z = make_float4(0.f, 0.f, 0.f, 0.f); M[0] = z; M[1] = z; M[2] = z; M[3] = z; }
-              }
-#else
               pc.root = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, false}; pc.leaf = pc.root; pc.root_t = 0.f;
-#endif
               if (P.accumulate && P.spp_begin != 0) {    // (a range that starts at sample 0 starts from nothing)
                 const float4 acc = *(reinterpret_cast<const float4 *>(P.image) + pix);
                 sr = acc.x; sg = acc.y; sb = acc.z;
-#if !defined(TDT_LAZY_ROOT) && !defined(TDT_NO_CARRY_IO) && !defined(TDT_MEMCARRY)
                 if (P.carry) {
                   const float4 *c = reinterpret_cast<const float4 *>(P.carry) + pix * 4;
                   const float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
                   pc.root = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z != 0.f}; pc.root_t = c1.w;
                   pc.leaf = {c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z != 0.f};
                 }
-#endif
               }
               if (s < s_end) state = ST_PRIMARY;
               else if (!P.accumulate) {               // zero samples: main() still stores sqrt(0/0) clamped
@@ -675,12 +557,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
         const float t_exit = hw_min(hw_min(hw_min(mxx, inf), mxy), mxz);
         t_octree_max = inf;
         if (t_exit >= t_enter) {
-#if defined(TDT_MEMCARRY)
-          float4 *const M = reinterpret_cast<float4 *>(P.carry) + pix * 4;      // the ray and its entry parameter: what the root call site's record is made of
-          M[0] = make_float4(r.ox, r.oy, r.oz, r.dx); M[1] = make_float4(r.dy, r.dz, 0.f, t_enter);
-#elif !defined(TDT_LAZY_ROOT)
           cube_hit_record(r, t_enter, P.min_x, P.min_y, P.min_z, P.scale, pc.root);
-#endif
           pc.root_t = t_enter;
           t_octree_max = t_exit;
         }
@@ -944,7 +821,11 @@ __global__ __launch_bounds__(256) void build_full_grid_kernel(const uint32_t *__
     v = value; m = (uint32_t)l;
     if (code == 1u && l < depth && v >= grid_v_bound(l)) ok = false;
   }
+#ifdef TDT_FULL_SH
+  uint32_t enc = (((uint32_t)depth - m) << 2) | code;  // depth - levels: what the lookup shifts the digits by (a PARENT: 0)
+#else
   uint32_t enc = (m << 2) | code;                      // (a PARENT: m = depth)
+#endif
   if (code == 2u) { enc |= v << 5; ok = ok && v < 2048u; }
   grid[e] = (uint16_t)enc;
   if (!ok) atomicOr(bad, 1u);
@@ -1476,23 +1357,6 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
   P.metal = (const uint32_t *)ctx->ssbo[TDT_SLOT_METAL]->dev; P.metal_dwords = dwords(ctx->ssbo[TDT_SLOT_METAL]);
   P.dielectric = (const uint32_t *)ctx->ssbo[TDT_SLOT_DIELECTRIC]->dev; P.dielectric_dwords = dwords(ctx->ssbo[TDT_SLOT_DIELECTRIC]);
   P.image = img->dev; P.carry = (float *)carry; P.carry_final = ctx->carry_final ? 1 : 0;
-#ifdef TDT_MEMCARRY
-  P.carry_keep = carry != nullptr ? 1 : 0;
-  if (!carry && (mode == 0 || mode == 1)) {            // the kernels keep the call sites' records in memory: a launch without a caller's carry uses the context's own block
-    const Cover k0 = cover_of(c, width, height);
-    const Tiles t0 = tiles_of(c, k0);
-    const size_t px = (size_t)img->w * (size_t)img->h, slots = (size_t)(t0.owned > 0 ? t0.owned : 0) * 1024;
-    const size_t need = (px > slots ? px : slots) * 16 * sizeof(float);
-    TDT_HIP(ctx, hipSetDevice(ctx->device));
-    if (ctx->frame_carry_bytes < need) {
-      if (ctx->frame_carry) { TDT_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->frame_carry); }
-      ctx->frame_carry = nullptr; ctx->frame_carry_bytes = 0;
-      TDT_HIP(ctx, hipMalloc(&ctx->frame_carry, need));
-      ctx->frame_carry_bytes = need;
-    }
-    P.carry = (float *)ctx->frame_carry;
-  }
-#endif
   if (mode == 2) P.carry_final = ctx->use_done ? 1 : 0;      // resolve: skip the pixels the frame's miss pre-pass finished (only then: tdt_dispatch_resolve on its own resolves every pixel)
   Cover k = cover_of(c, width, height);
   Tiles t = tiles_of(c, k);
@@ -1785,11 +1649,7 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
       // UNIT builds do not multiply by a scale of exactly 1.0f (x * 1.0f is x).  The probe launch of a two-phase frame runs the build
       // that multiplies — the same bits, and the short launch then has a row of its own in profiler statistics instead of halving the
       // average of the launches that do the work
-#ifdef TDT_SLIM2
       const bool unit = P.scale == 1.0f && P.inv_scale == 1.0f && P.min_x != 0.0f && P.min_y != 0.0f && P.min_z != 0.0f && !ctx->probe_launch;      // (a zero corner component: see the in-octree test)
-#else
-      const bool unit = P.scale == 1.0f && P.inv_scale == 1.0f && !ctx->probe_launch;
-#endif
       const int form = pow2 ? tdt::FORM_POW2 : tdt::FORM_TABLE;
       TraceFn fn = nullptr;
       if (brick) fn = find_variant(form, P.max_depth, false, false, true, unit);

@@ -485,6 +485,7 @@ TDT_DEV void build_top_grid(const uint16_t *lds, uint32_t lds_nodes, int depth, 
 constexpr uint32_t kCostStep = 3, kCostEvent = 64, kCostRayStep = 7;      // (kCostRayStep: per step when the levels are not counted — 3 + the ~4 levels a step used to visit)
 constexpr uint32_t kEventWindow = 1024;   // rays after which the adaptive event threshold's running counts are halved
 constexpr int kMemoLevels = 9;
+constexpr int kBrickMemoLevels = 3;   // BRICK builds (see trace_kernel): >= 2, the levels their jump covers beyond kMemoFirst
 // levels of the LDS jump table: 4 for trees inside the LDS table, 5 for the others (see Grid<GL>) — except FORM_TABLE trees outside
 // it, which keep 4: the thresholds the table's band is computed from are staged for the first kThrTopCells cells only (levels 1-4
 // of a breadth-first tree: at most 585 cells), beside the 82 KB node table
@@ -568,8 +569,13 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
       // the whole lookup: levels visited, the cell's digits and what it holds (see build_full_grid_kernel)
       const uint32_t xg = (uint32_t)tg;
       const uint32_t g = ns.full[(xg << (2 * DEPTH)) | (Yi << DEPTH) | Zi];
+#ifdef TDT_FULL_SH
+      const uint32_t sh = (g >> 2) & 7u;                                      // DEPTH - levels (build_full_grid_kernel)
+      const float ipd = __uint_as_float(((127u - (uint32_t)DEPTH) << 23) + (sh << 23));      // 2^-levels
+#else
       const uint32_t mg = (g >> 2) & 7u, sh = (uint32_t)DEPTH - mg;
       const float ipd = __uint_as_float((127u - mg) << 23);                   // 2^-levels
+#endif
       gx = (float)(xg >> sh) * ipd; gy = (float)(Yi >> sh) * ipd; gz = (float)(Zi >> sh) * ipd;
       inv_pow_depth = ipd;
       value = g >> 5;
@@ -728,14 +734,17 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
     }
 #pragma unroll
     for (int l = kMemoFirst + 1; l < kFirstAfterJump; l++) {
-      if (code == 1u && l <= depth) level(l, &memo.key[l - kMemoFirst - 1], &memo.val[l - kMemoFirst - 1]);
+      if (code == 1u && l <= depth) {
+        if (l - kMemoFirst - 1 < CL) level(l, &memo.key[l - kMemoFirst - 1 < CL ? l - kMemoFirst - 1 : 0], &memo.val[l - kMemoFirst - 1 < CL ? l - kMemoFirst - 1 : 0]);
+        else level(l, nullptr, nullptr);               // (a build with fewer memo levels than the jump covers)
+      }
     }
   }
 #pragma unroll
   for (int l = kFirstAfterJump; l <= kMemoFirst + CL; l++) {
     if (code == 1u && l <= depth) level(l, &memo.key[l - kMemoFirst - 1], &memo.val[l - kMemoFirst - 1]);
   }
-  for (int l = kMemoFirst + CL + 1; code == 1u && l <= depth; l++) level(l, nullptr, nullptr);
+  for (int l = (kMemoFirst + CL + 1 > kFirstAfterJump ? kMemoFirst + CL + 1 : kFirstAfterJump); code == 1u && l <= depth; l++) level(l, nullptr, nullptr);      // (levels past the memo; never one the jump covered)
   const int m = 31 - __builtin_clz(qx);               // levels visited
   qx ^= 1u << m;
   const float ipd = __uint_as_float((uint32_t)(127 - m) << 23);             // 2^-m = inv_pow_depth after m halvings

@@ -47,9 +47,6 @@ struct TraceParams {
   int32_t event_threshold;     // > 0: fixed number of lanes that must wait for the event code; 0: adaptive
   float event_clamp;           // upper clamp of the adaptive threshold
   float event_k;               // adaptive threshold: r = C_t / (2 C_e) of the model in trace_kernel
-#ifdef TDT_MEMCARRY
-  int32_t carry_keep;          // 1: a pixel that continues running sums (accumulate, spp_begin > 0) also continues the records in `carry`; 0: every pixel starts from zero records
-#endif
 #ifdef TDT_STATS
   unsigned long long *stats;   // -DTDT_STATS builds only (tools/loss_budget.py): pass / lane statistics of the product kernels, see TDT_ST in trace_kernel
 #endif

@@ -1,8 +1,9 @@
-"""copy what tools/profile_r03.sh (ROUND=r02: profile_r02.sh) left under gpurun_out/<tag>/ into profiles/ under the round's names (r02_*) and refresh
+"""copy what tools/profile_r04.sh (ROUND=r03 / r02: the earlier rounds' scripts) left under gpurun_out/<tag>/ into profiles/ under the round's names (r04_*) and refresh
 profiles/traffic.json; usage: python tools/collect_profiles.py <tag> [--bench-only]"""
 import glob, json, os, shutil, sys
 tag = sys.argv[1]
-RND = os.environ.get("ROUND", "r03")
+RND = os.environ.get("ROUND", "r04")
+PREV = {"r04": "_r03", "r03": "_r02"}.get(RND, "_prev")
 bench_only = "--bench-only" in sys.argv
 src = os.path.join("gpurun_out", tag)
 dst = "profiles"
@@ -29,12 +30,18 @@ for c in (2, 3, 5, 0):
         json.load(open(p))
         shutil.copy(p, os.path.join(dst, RND + "_config%d_pmc_tcc.json" % c))
 shutil.copy(os.path.join(src, "pmc_summary.json"), os.path.join(dst, RND + "_pmc_summary.json"))
+for p in glob.glob(os.path.join(src, "stats_c*_*.json")):      # pass statistics of the product kernels (tools/loss_budget.py collect)
+    if os.path.getsize(p):
+        shutil.copy(p, os.path.join(dst, RND + "_" + os.path.basename(p)))
+for s_, d_ in (("demo_time.txt", RND + "_demo_time.txt"),):
+    if os.path.exists(os.path.join(src, s_)):
+        shutil.copy(os.path.join(src, s_), os.path.join(dst, d_))
 tr = json.load(open(os.path.join(dst, "traffic.json")))
 for c in (2, 3, 5, 0):
     t = json.load(open(os.path.join(dst, RND + "_config%d_pmc_tcc.json" % c)))["counters"]
     for k in ("config%d_spp64_gpus1" % c, "config%d_spp4_gpus1" % c):      # keep the previous round's figures beside the new ones
-        if k in tr and (k + "_r02") not in tr:
-            tr[k + "_r02"] = tr[k]
+        if k in tr and (k + PREV) not in tr:
+            tr[k + PREV] = tr[k]
     tr["config%d_spp%d_gpus1" % (c, 4 if c == 0 else 64)] = {"FETCH_SIZE_KB": t["FETCH_SIZE"], "WRITE_SIZE_KB": t["WRITE_SIZE"],
                                        "hbm_bytes_per_launch": int((2 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024),
                                        "TCC_HIT_sum": t["TCC_HIT_sum"], "TCC_MISS_sum": t["TCC_MISS_sum"],

@@ -2,7 +2,7 @@
 """Registers, scratch, occupancy and LDS of every kernel of csrc/tdt_rt.hip as the compiler reports them
 (`-Rpass-analysis=kernel-resource-usage`, the build's own flags; cross-compiles without a GPU, ~25 s).
 
-    python tools/kernel_resources.py [out.txt]      # default: profiles/r03_kernel_resources.txt
+    python tools/kernel_resources.py [out.txt]      # default: profiles/r04_kernel_resources.txt
 
 tests/test_kernel_resources.py asserts on the same rows: no trace kernel may spill to scratch, drop below 4 waves per SIMD or
 outgrow the CU's 160 KiB of LDS — a feature that costs registers has to fail a test, not silently lose 15 %."""
@@ -57,7 +57,7 @@ def table(rows):
 
 
 if __name__ == "__main__":
-    dst = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_kernel_resources.txt")
+    dst = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04_kernel_resources.txt")
     rows = collect()
     head = ("# hipcc -Rpass-analysis=kernel-resource-usage over csrc/tdt_rt.hip with the build's flags (tools/kernel_resources.py).\n"
             "# trace_kernel<COUNT, FORM (0 literal / 1 pow2 / 2 table), DEPTH, RESIDENT, SAFEV, FULL, UNIT, BRICK>; 1024-thread blocks: 128 VGPRs = 4 waves/SIMD is the cap.\n")

@@ -11,7 +11,7 @@ those (per loop pass: cross-checked against the hand count of the fast path); ac
 SQ_THREAD_CYCLES_VALU.  The budget is in units of SIMD lane-slots: 1024 SIMDs x launch time x clock / 2 cycles x 64 lanes.
 
     TDT_LIB=build_ab/lib_stats.so TDT_STATS_SKIP_PROBE=1 python tools/loss_budget.py collect --config 2 --mode fresh > stats.json
-    python tools/loss_budget.py report --stats-dir gpurun_out/r04/ --pmc profiles/r03_pmc_summary.json
+    python tools/loss_budget.py report --stats-dir gpurun_out/r04/ --pmc profiles/r04_pmc_summary.json
 """
 import argparse, glob, json, os, sys
 
@@ -126,7 +126,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     sub = ap.add_subparsers(dest="cmd", required=True)
     c = sub.add_parser("collect"); c.add_argument("--config", type=int, default=2); c.add_argument("--mode", default="fresh", choices=("fresh", "replay"))
-    r = sub.add_parser("report"); r.add_argument("--stats-dir", required=True); r.add_argument("--pmc", default=os.path.join(ROOT, "profiles", "r03_pmc_summary.json"))
+    r = sub.add_parser("report"); r.add_argument("--stats-dir", required=True); r.add_argument("--pmc", default=os.path.join(ROOT, "profiles", "r04_pmc_summary.json"))
     r.add_argument("--isa", default=os.path.join(ROOT, "profiles", "r04_isa_regions.json")); r.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_loss_budget.json"))
     r.add_argument("--clock-ghz", type=float, default=2.4)
     a = ap.parse_args()
