@@ -801,7 +801,7 @@ __global__ __launch_bounds__(256) void selftest_index_kernel(float inv_cell_coun
 }
 
 // The whole-depth table of FULL builds (see tree_lookup_pow2): entry (x, y, z digits of a finest-level voxel position) = what
-// treeLookup's descent with those child digits ends on.  16 bits: levels << 2 | code, and for a LEAF its value << 5 (the only
+// treeLookup's descent with those child digits ends on.  16 bits: (depth - levels) << 2 | code, and for a LEAF its value << 5 (the only
 // value a traversal step uses; a PARENT can only be what the last level holds).  *bad is raised when the tree does not fit the
 // claim the table rests on (a PARENT of a level that feeds a later x decision at or above grid_v_bound) or a material index
 // does not fit 11 bits.
@@ -821,11 +821,7 @@ __global__ __launch_bounds__(256) void build_full_grid_kernel(const uint32_t *__
     v = value; m = (uint32_t)l;
     if (code == 1u && l < depth && v >= grid_v_bound(l)) ok = false;
   }
-#ifdef TDT_FULL_SH
-  uint32_t enc = (((uint32_t)depth - m) << 2) | code;  // depth - levels: what the lookup shifts the digits by (a PARENT: 0)
-#else
-  uint32_t enc = (m << 2) | code;                      // (a PARENT: m = depth)
-#endif
+  uint32_t enc = (((uint32_t)depth - m) << 2) | code;  // depth - levels: what the lookup shifts the digits by, and the exponent of the cell size above 2^-depth (a PARENT: 0)
   if (code == 2u) { enc |= v << 5; ok = ok && v < 2048u; }
   grid[e] = (uint16_t)enc;
   if (!ok) atomicOr(bad, 1u);
@@ -866,7 +862,8 @@ __global__ __launch_bounds__(256) void build_bricks_kernel(const uint32_t *__res
   const uint32_t k = band >= -11 ? 0u : (uint32_t)(-11 - band);           // band 2^-(11 + k) >= 2^band, k in 0..7
   if (code != 1u) {                                   // EMPTY / LEAF within five levels
     if (code == 2u && v >= (1u << 23) && tid == 0) atomicOr(bad, 1u);
-    if (tid == 0) grid32[e] = (code == 2u ? v << 6 : 0u) | (m << 2) | code | (k << 29);
+    // (builds with bricks: depth - levels instead of the levels, as in the brick entries — what the lookup shifts the digits by)
+    if (tid == 0) grid32[e] = (code == 2u ? v << 6 : 0u) | ((BL == 0 ? m : (uint32_t)(5 + BL) - m) << 2) | code | (k << 29);
     return;
   }
   if (BL == 0) {                                      // no bricks: the entry hands the level-6 cell to the walk
@@ -917,7 +914,7 @@ __global__ __launch_bounds__(256) void build_bricks_kernel(const uint32_t *__res
       mm = 6u + (uint32_t)j;
     }
     if (cd == 2u && val >= 1024u) atomicOr(&s_inv, 1u);
-    bricks[(size_t)e * kEntries + s] = (uint16_t)((cd == 2u ? val << 6 : 0u) | (mm << 2) | cd);
+    bricks[(size_t)e * kEntries + s] = (uint16_t)((cd == 2u ? val << 6 : 0u) | (((uint32_t)(5 + BL) - mm) << 2) | cd);      // depth - levels | code, a LEAF's value above
   }
   __syncthreads();
   if (tid == 0) {

@@ -530,7 +530,7 @@ constexpr int kMemoFirst = 3;       // levels 1..3 = cells 0..72 at most: always
 // decisions of levels 6.. add the coordinate to (31: the cells of a level below this position do not share one — the wave
 // walks).  A traversal step is then one LDS read and one 2-byte load instead of a table read, three or four memo compares and
 // as many dependent L2 round trips.  Table entries (32 bits): PARENT 1 | e6 << 2 | e7 << 7 | e8 << 12 | e9 << 17 | k << 29; EMPTY /
-// LEAF code | levels << 2 | value << 6 | k << 29.  Brick entries (16 bits): levels << 2 | code, and a LEAF's value << 6 (a material
+// LEAF code | (depth - levels) << 2 | value << 6 | k << 29 (depth 10, no bricks: levels << 2).  Brick entries (16 bits): (depth - levels) << 2 | code, and a LEAF's value << 6 (a material
 // index >= 1024 below a position: it walks).  k: the position's own band — the x decisions of its five levels are the
 // coordinate's digits unless 32 c is within 2^-(11 + k) of an integer, where 2^-(11 + k) >= 2^(5 - l) ulp(v_l + f) for the
 // cell index v_l each level l really uses (the table-wide 2^-11 of the 16-bit tables assumes the largest index the bounds allow,
@@ -569,13 +569,8 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
       // the whole lookup: levels visited, the cell's digits and what it holds (see build_full_grid_kernel)
       const uint32_t xg = (uint32_t)tg;
       const uint32_t g = ns.full[(xg << (2 * DEPTH)) | (Yi << DEPTH) | Zi];
-#ifdef TDT_FULL_SH
-      const uint32_t sh = (g >> 2) & 7u;                                      // DEPTH - levels (build_full_grid_kernel)
+      const uint32_t sh = (g >> 2) & 7u;                                      // DEPTH - levels (build_full_grid_kernel stores it that way: one subtraction less per step)
       const float ipd = __uint_as_float(((127u - (uint32_t)DEPTH) << 23) + (sh << 23));      // 2^-levels
-#else
-      const uint32_t mg = (g >> 2) & 7u, sh = (uint32_t)DEPTH - mg;
-      const float ipd = __uint_as_float((127u - mg) << 23);                   // 2^-levels
-#endif
       gx = (float)(xg >> sh) * ipd; gy = (float)(Yi >> sh) * ipd; gz = (float)(Zi >> sh) * ipd;
       inv_pow_depth = ipd;
       value = g >> 5;
@@ -619,8 +614,8 @@ TDT_DEV bool tree_lookup_pow2(const TraceParams &P, const NodeSource &ns, float 
         ent = static_cast<const uint16_t *>(ns.bricks)[bi];
         xd |= xlow;
       }
-      const uint32_t mg = (ent >> 2) & 15u, sh = (uint32_t)DEPTH - mg;
-      const float ipd = __uint_as_float((127u - mg) << 23);                   // 2^-levels
+      const uint32_t sh = (ent >> 2) & 15u;                                   // DEPTH - levels (as build_bricks_kernel stores it)
+      const float ipd = __uint_as_float(((127u - (uint32_t)DEPTH) << 23) + (sh << 23));      // 2^-levels
       gx = (float)(xd >> sh) * ipd; gy = (float)(Yi >> sh) * ipd; gz = (float)(Zi >> sh) * ipd;
       inv_pow_depth = ipd;
       value = ent >> 6;

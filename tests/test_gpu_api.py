@@ -93,6 +93,19 @@ def test_gpu_turned_cameras_vs_reference_render_under_switches(name, switch, mon
         r.close()
 
 
+def test_pass_statistics_are_refused_by_the_product_library():
+    """tdt_debug_stats belongs to -DTDT_STATS builds (tools/loss_budget.py); the product library must say so, not return zeros."""
+    if os.environ.get("TDT_LIB"):
+        pytest.skip("an alternative build is loaded")
+    ctx = rt.Context()
+    try:
+        with pytest.raises(rt.TdtError) as e:
+            ctx.stats()
+        assert e.value.code == rt.ERR_INVALID_OPERATION and "TDT_STATS" in str(e.value)
+    finally:
+        ctx.close()
+
+
 def test_resolve_on_its_own_resolves_every_pixel():
     """tdt_dispatch_resolve is main()'s sqrt / clamp / store for EVERY covered pixel (include/tdt_rt.h), whatever alpha the caller's
     running sums carry — only the library's own resolve of a frame whose miss pre-pass ran skips the pixels that pass finished."""
