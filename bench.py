@@ -166,7 +166,11 @@ def physical_roofline(wkey):
     return {"bound": "valu", "frac": round(v["issue_util"] * v["lane_util"], 4), "issue_util": v["issue_util"], "lane_util": v["lane_util"],
             "unit": "fraction of peak VALU lane throughput (issue-slot use x live lanes)", "salu_per_valu": round(v["salu_instructions"] / v["valu_wave_instructions"], 4)
             if v.get("salu_instructions") and v.get("valu_wave_instructions") else None,
-            "kernel_ms_under_pmc": v.get("kernel_ms_under_pmc"), "source": src, "formula": v.get("formula")}
+            "kernel_ms_under_pmc": v.get("kernel_ms_under_pmc"), "source": src, "formula": v.get("formula"),
+            "note": ("utilisation of a NOMINAL issue peak (one wave64 VALU instruction per 2 cycles per SIMD).  On gfx950 only add / sub / mul / fma / logic / "
+                     "mov issue at that rate; compares, min / max, converts, shifts left, three-operand integer forms and every VALU instruction with "
+                     "an SGPR operand take about 4.3 cycles, transcendentals 8.2 (tools/micro/pipe_model.hip), and the traversal step is about half "
+                     "such instructions — round 4 made the frame faster by REMOVING instructions, which lowers this figure; see DESIGN.md §4")}
 
 
 def single_process_leg(args):

@@ -1,8 +1,11 @@
 #!/bin/bash
 # usage: tools/profile_r04.sh <tag>   (on the GPU box) -> gpurun_out/<tag>/: rocprofv3 kernel stats, SQ + TCC counter passes (separate
 # --pmc runs, never combined with other trace domains), bench JSON lines.  Copy the summaries into profiles/.
-TAG=$1; export TMPDIR=/tmp
+# A second argument selects a part (a gpurun call is limited to 20 minutes): `pmc` = the counter passes, `bench` = kernel stats, bench lines,
+# pass statistics; none = both.
+TAG=$1; PART=${2:-all}; export TMPDIR=/tmp
 O=gpurun_out/$TAG; mkdir -p $O
+if [ $PART = all ] || [ $PART = pmc ]; then
 SQ_A="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_INSTS_SALU"
 SQ_B="SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_BRANCH SQ_INSTS_LDS SQ_INST_CYCLES_VMEM_RD"
 for C in 2 3 5 0; do
@@ -21,6 +24,8 @@ for C in 2 3 5 0; do
   python3 tools/pmc_summary.py $O/tcc_c${C}/FETCH_SIZE $O/tcc_c${C}/WRITE_SIZE $O/tcc_c${C}/TCC_HIT_sum $O/tcc_c${C}/TCP_TCC_READ_REQ_sum > $O/tcc_c${C}.summary.txt
   echo "tcc c$C done"
 done
+fi
+if [ $PART = all ] || [ $PART = bench ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-strong --no-single-process --no-target --no-reference-default > $O/bench_stats_c2.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3 -- python3 bench.py --steps 6 --warmup 2 --config 3 --no-cpu-baseline --no-strong --no-single-process > $O/bench_stats_c3.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5 -- python3 bench.py --steps 6 --warmup 2 --config 5 --no-cpu-baseline --no-strong --no-single-process > $O/bench_stats_c5.log 2>&1
@@ -37,4 +42,5 @@ for C in 2 3 5 0; do for M in fresh replay; do
   TDT_LIB=$PWD/build_ab/lib_stats.so TDT_STATS_SKIP_PROBE=1 timeout -k 10 300 python3 tools/loss_budget.py collect --config $C --mode $M > $O/stats_c${C}_${M}.json 2> $O/stats_c${C}_${M}.err
 done; done
 echo "pass statistics done"
+fi
 ls $O
