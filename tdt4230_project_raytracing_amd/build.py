@@ -12,7 +12,7 @@ INCLUDE = os.path.join(ROOT, "include")
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 # -ffp-contract=off and IEEE divide/sqrt are PARITY flags, not tuning knobs: the reference's
-# arithmetic is unfused and correctly rounded (DESIGN.md "Numerics").
+# arithmetic is unfused and correctly rounded (DESIGN.md §4 "Parity flags").
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
              "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wextra",
              # measured: SLP-packed v_pk_*_f32 costs 6 % here (register-pair shuffles around scalar vec3 code)

@@ -84,7 +84,6 @@ struct tdt_ctx {
   bool phase_timing; hipEvent_t phase_ev[4]; int phase_n;   // tdt_debug_phase_timing: events around the launches of the last frame
   uint32_t *present; size_t present_bytes;   // staging of tdt_image_read_rgba8
   uint32_t *pixel_log; size_t pixel_log_u32;   // TDT_PIXEL_LOG diagnostics (instrumented dispatches only)
-  int div_checked[2]; bool div_ok;   // image size whose primary-ray divisors div_check_kernel has verified, and its verdict
   unsigned long long *stats;    // tdt_debug_stats: pass statistics of -DTDT_STATS builds (null otherwise)
   int last_variant[6];  // tdt_debug_last_variant: the build the last trace launch ran
   bool no_specialise;   // TDT_NO_SPECIALISE=1: never pick a scene-specialised kernel (A/B testing)

@@ -165,9 +165,6 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   }
   ns.cells = __builtin_amdgcn_make_buffer_rsrc((void *)P.cells, 0, (int)((P.cells_dwords >> 1) << 3), 0x00020000);
   const MatSource ms = material_source(P);
-#ifdef TDT_FAST_PRIMARY_DIV
-  const PrimaryDiv pdiv = primary_div(P);
-#endif
 #ifdef TDT_STATS
   __shared__ uint32_t s_stats[(TDT_BLOCK / 64) * STAT_COUNT];
   uint32_t *const s_stat_row = &s_stats[(threadIdx.x >> 6) * STAT_COUNT];
@@ -525,11 +522,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     TDT_MARK(primary);
     TDT_ST(STAT_PRIMARY_PASS, __ballot(state == ST_PRIMARY));
     if (state == ST_PRIMARY) {                        // rc:240-245
-#ifdef TDT_FAST_PRIMARY_DIV
-      r = primary_ray(P, x, y, s, pdiv);
-#else
       r = primary_ray(P, x, y, s);
-#endif
       loop_count = 0; ar = 1.f; ag = 1.f; ab = 1.f;
       state = ST_NEWRAY;
     }
@@ -647,19 +640,12 @@ __global__ __launch_bounds__(256) void resolve_kernel(const TraceParams P) {
 __global__ __launch_bounds__(256) void miss_prepass_kernel(const TraceParams P, uint8_t *__restrict__ done) {
   int x, y; size_t pix;
   const bool covered = pixel_of_thread(P, x, y, pix);
-#ifdef TDT_FAST_PRIMARY_DIV
-  const PrimaryDiv pdiv = primary_div(P);
-#endif
   const size_t slot = (size_t)(blockIdx.x >> 2) * 1024u + (size_t)((blockIdx.x & 3) * 256 + threadIdx.x);
   bool all_miss = covered;
   float sr = 0.f, sg = 0.f, sb = 0.f;
   const float inf = __builtin_inff();
   for (int s = 0; s < P.samples_per_pixel && __ballot(all_miss) != 0ull; s++) {
-#ifdef TDT_FAST_PRIMARY_DIV
-    const Ray r = primary_ray(P, x, y, s, pdiv);      // rc:240-245 (PRIMARY)
-#else
     const Ray r = primary_ray(P, x, y, s);            // rc:240-245 (PRIMARY)
-#endif
     float ix, iy, iz;
     q_rcp3(r.dx, r.dy, r.dz, ix, iy, iz);             // NEWRAY: OctreeHit's root test rc:399-408
     const float lx = (P.min_x + -r.ox) * ix, ly = (P.min_y + -r.oy) * iy, lz = (P.min_z + -r.oz) * iz;
@@ -748,17 +734,6 @@ __global__ __launch_bounds__(1024) void filter_write_kernel(const uint32_t *__re
     const uint32_t first = blockIdx.x * kFilterChunk + r * 1024u, valid = first >= n ? 0u : (n - first < 1024u ? n - first : 1024u);
     base += t; pad += valid - t;
   }
-}
-
-// div_by_uniform against the IEEE division for one divisor: every float bit pattern in [0, max_bits] as the numerator (see primary_div).
-__global__ __launch_bounds__(256) void div_check_kernel(float b, uint32_t max_bits, uint32_t *__restrict__ bad) {
-  const float r = rcp_core(b);
-  uint32_t n = 0;
-  for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i <= (unsigned long long)max_bits; i += (unsigned long long)gridDim.x * 256u) {
-    const float a = __uint_as_float((uint32_t)i);
-    n += (__float_as_uint(div_by_uniform(a, b, r)) != __float_as_uint(a / b)) ? 1u : 0u;
-  }
-  if (__ballot(n != 0u) != 0ull && n != 0u) atomicOr(bad, 1u);
 }
 
 // Re-encode the first n nodes of the cells payload as one dword each for the LDS table (NodeSource).
@@ -1393,28 +1368,6 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
   else return fail(ctx, TDT_ERR_INVALID_OPERATION,
                    "bound image is neither camera.image_width x image_height nor a 32 x 32*tiles tile buffer");
   P.spp_begin = spp_begin; P.spp_count = spp_count; P.mode = mode; P.total_spp = total_spp;
-#ifdef TDT_FAST_PRIMARY_DIV
-  if (mode != 2) {      // the primary ray's divisions by image_width - 1 / image_height - 1 through a hoisted reciprocal: verified per divisor, once (see primary_div)
-    if (ctx->div_checked[0] != c->image_width || ctx->div_checked[1] != c->image_height) {
-      ctx->div_checked[0] = c->image_width; ctx->div_checked[1] = c->image_height; ctx->div_ok = false;
-      const float bw = (float)(c->image_width - 1), bh = (float)(c->image_height - 1);
-      if (c->image_width >= 3 && c->image_height >= 3 && c->image_width <= (1 << 22) && c->image_height <= (1 << 22)) {
-        TDT_HIP(ctx, hipSetDevice(ctx->device));
-        if (!ctx->scan) TDT_HIP(ctx, hipMalloc((void **)&ctx->scan, 4 * sizeof(uint32_t)));
-        TDT_HIP(ctx, hipMemsetAsync(ctx->scan + 3, 0, sizeof(uint32_t), ctx->stream));
-        uint32_t mw, mh; { const float tw = bw + 2.0f, th = bh + 2.0f; std::memcpy(&mw, &tw, 4); std::memcpy(&mh, &th, 4); }
-        hipLaunchKernelGGL(tdt::div_check_kernel, dim3(4096), dim3(256), 0, ctx->stream, bw, mw, ctx->scan + 3);
-        hipLaunchKernelGGL(tdt::div_check_kernel, dim3(4096), dim3(256), 0, ctx->stream, bh, mh, ctx->scan + 3);
-        TDT_HIP(ctx, hipGetLastError());
-        uint32_t flag = 1;
-        TDT_HIP(ctx, hipMemcpyAsync(&flag, ctx->scan + 3, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
-        TDT_HIP(ctx, hipStreamSynchronize(ctx->stream));      // once per image size, not per frame
-        ctx->div_ok = flag == 0;
-      }
-    }
-    if (ctx->div_ok) P.mode |= 0x100;
-  }
-#endif
   P.event_threshold = ctx->event_threshold;   // 0: adaptive (see trace_kernel)
   P.event_clamp = (float)ctx->event_clamp;
   {  // r of the adaptive event threshold (see trace_kernel): 0.10 up to 1.4 MiB of cells, 0.35 from 5 MiB on (refitted twice in round 2:
@@ -1764,7 +1717,7 @@ int tdt_ctx_create(int device_id, void *stream, tdt_ctx **out) {
   if (!ctx) return fail(nullptr, TDT_ERR_HIP, "out of host memory");
   ctx->device = device_id;
   for (auto &s : ctx->ssbo) s = nullptr;
-  ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr; ctx->queue = nullptr; ctx->packed = nullptr; ctx->packed_of = nullptr; ctx->packed_version = 0; ctx->present = nullptr; ctx->present_bytes = 0; ctx->frame_carry = nullptr; ctx->frame_carry_bytes = 0; ctx->probe_launch = false; ctx->phase_timing = false; ctx->phase_n = 0; ctx->pixel_log = nullptr; ctx->pixel_log_u32 = 0; ctx->stats = nullptr; ctx->div_checked[0] = ctx->div_checked[1] = -1; ctx->div_ok = false; ctx->slot_cost = ctx->slot_acc = ctx->slot_order = ctx->order_hist = nullptr; ctx->tile_capacity = ctx->cost_tiles = 0; ctx->cost_dispatches = 0;
+  ctx->atomic0 = nullptr; ctx->image0 = nullptr; ctx->counters = nullptr; ctx->queue = nullptr; ctx->packed = nullptr; ctx->packed_of = nullptr; ctx->packed_version = 0; ctx->present = nullptr; ctx->present_bytes = 0; ctx->frame_carry = nullptr; ctx->frame_carry_bytes = 0; ctx->probe_launch = false; ctx->phase_timing = false; ctx->phase_n = 0; ctx->pixel_log = nullptr; ctx->pixel_log_u32 = 0; ctx->stats = nullptr; ctx->slot_cost = ctx->slot_acc = ctx->slot_order = ctx->order_hist = nullptr; ctx->tile_capacity = ctx->cost_tiles = 0; ctx->cost_dispatches = 0;
   { const char *nc = getenv("TDT_NO_COST_ORDER"); ctx->no_cost_order = nc && nc[0] == '1';
     const char *fs = getenv("TDT_ORDER_SMOOTH"); ctx->force_smooth = fs ? atoi(fs) : -1;
     ctx->no_cost_accum = getenv("TDT_NO_COST_ACCUM") != nullptr;

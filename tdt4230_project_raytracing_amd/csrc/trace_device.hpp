@@ -921,29 +921,8 @@ TDT_DEV bool scatter(const MatSource &ms, const Ray &r, const Hit &h, const MatR
   return false;
 }
 
-// a / b for a divisor b that is the same for every lane and every call (image_width - 1, image_height - 1): the correctly rounded
-// reciprocal r = RN(1 / b) is computed once, and q0 = RN(a r), q = RN(q0 + RN(a - b q0) r) — div_core with the reciprocal hoisted — is the
-// correctly rounded quotient (Markstein's correction step: it needs r correctly rounded — rcp_core, checked on all inputs — and no
-// under / overflow).  As everywhere in this file that is not taken on trust: before a context uses it for a divisor, div_check_kernel
-// compares it with the IEEE division for EVERY numerator the trace can form for that divisor (all floats in [0, b + 2]), once per image
-// size; a divisor that fails (none is known) or lies outside the window keeps the IEEE division.  3 instructions instead of ~11, twice per
-// primary ray.
-struct PrimaryDiv { float bw, rw, bh, rh; bool fast; };
-TDT_DEV float div_by_uniform(float a, float b, float r) { const float q0 = a * r; return __builtin_fmaf(__builtin_fmaf(-b, q0, a), r, q0); }
-TDT_DEV PrimaryDiv primary_div(const TraceParams &P) {
-  PrimaryDiv d;
-  d.bw = (float)(P.image_width - 1); d.bh = (float)(P.image_height - 1);
-  d.fast = (P.mode & 0x100) != 0;                     // (launch(): both divisors verified for this context)
-  d.rw = d.fast ? rcp_core(d.bw) : 0.0f; d.rh = d.fast ? rcp_core(d.bh) : 0.0f;
-  return d;
-}
-
 // primary ray of sample s at pixel (px,py): rc:240-245, CameraGetRay rc:304-307
-#ifdef TDT_FAST_PRIMARY_DIV
-TDT_DEV Ray primary_ray(const TraceParams &P, int px, int py, int s, const PrimaryDiv &pd) {
-#else
 TDT_DEV Ray primary_ray(const TraceParams &P, int px, int py, int s) {
-#endif
   float x = (float)px, y = (float)py, fs = (float)s;
   const float K = 0.2f * .1031f;
   // pixel coordinates and sample indices are non-negative, so every fract argument here is too
@@ -953,14 +932,8 @@ TDT_DEV Ray primary_ray(const TraceParams &P, int px, int py, int s) {
   float a2 = f_fract_nonneg(K * x), b2 = f_fract_nonneg(K * (y + fs));
   float d2 = (a2 + 33.33f) * (a2 + b2) + a2 * (b2 + 33.33f);
   float h2 = f_fract_nonneg(((a2 + d2) + (b2 + d2)) * (a2 + d2));
-#ifdef TDT_FAST_PRIMARY_DIV
-  float u, v;
-  if (pd.fast) { u = div_by_uniform(x + h1, pd.bw, pd.rw); v = div_by_uniform(y + h2, pd.bh, pd.rh); }
-  else { u = (x + h1) / pd.bw; v = (y + h2) / pd.bh; }
-#else
   float u = (x + h1) / (float)(P.image_width - 1);
   float v = (y + h2) / (float)(P.image_height - 1);
-#endif
   float rx = (P.hor[0] * u + P.llc[0]) + (v * P.ver[0] + -P.org[0]);
   float ry = (P.hor[1] * u + P.llc[1]) + (v * P.ver[1] + -P.org[1]);
   float rz = (P.hor[2] * u + P.llc[2]) + (v * P.ver[2] + -P.org[2]);

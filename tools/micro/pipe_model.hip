@@ -11,12 +11,14 @@
 #define H(i)  asm volatile("v_max_f32 %0, %0, %1" : "+v"(h[i]) : "v"(b))
 #define T(i)  asm volatile("v_rcp_f32 %0, %0" : "+v"(h[i]))
 #define S(i)  asm volatile("s_add_u32 s20, s20, 1" ::: "s20", "scc")
+typedef float f2_ __attribute__((ext_vector_type(2)));
+#define PK(i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(pk[i]) : "v"(pk[((i) + 1) & 7]))
 
 template <int OP>
 __global__ __launch_bounds__(1024) void k(float *out, int iters, float fs) {
-  float f[8], h[8]; unsigned u[8];
+  float f[8], h[8]; unsigned u[8]; f2_ pk[8];
 #pragma unroll
-  for (int i = 0; i < 8; i++) { f[i] = threadIdx.x * 1e-3f + i; h[i] = f[i] + 0.5f; u[i] = threadIdx.x * 7u + i; }
+  for (int i = 0; i < 8; i++) { f[i] = threadIdx.x * 1e-3f + i; h[i] = f[i] + 0.5f; u[i] = threadIdx.x * 7u + i; pk[i] = {1.0f + f[i] * 1e-6f, 1.0f - f[i] * 1e-6f}; }
   const float b = 1.0001f, c = 0.5f;
   for (int it = 0; it < iters; it++) {
 #pragma unroll
@@ -36,6 +38,12 @@ __global__ __launch_bounds__(1024) void k(float *out, int iters, float fs) {
         if (OP == 10) { S(i); }
         if (OP == 11) { S(i); F(i); }
         if (OP == 12) { S(i); H(i); }
+        if (OP == 60) { PK(i); }
+        if (OP == 61) { PK(i); F(i); }
+        if (OP == 62) { PK(i); F(i); FM(i); }
+        if (OP == 63) { PK(i); F(i); PK((i + 3) & 7); FM(i); }        // 2 PK + 2 F: six flops
+        if (OP == 64) { F(i); FM(i); F((i + 1) & 7); FM((i + 1) & 7); F((i + 2) & 7); FM((i + 2) & 7); }   // 6 F: the same six flops
+        if (OP == 65) { PK(i); H(i); }
         if (OP == 13) { F(i); F((i + 1) & 7); F((i + 2) & 7); F((i + 3) & 7); H(i); H((i + 4) & 7); }   // 4 F + 2 H, grouped
         // ---- classes of single instructions ----
         if (OP == 20) asm volatile("v_add_f32 %0, s20, %0" : "+v"(f[i]) :: "s20");                     // VOP2, SGPR src0
@@ -83,7 +91,7 @@ __global__ __launch_bounds__(1024) void k(float *out, int iters, float fs) {
   }
   float s = fs; unsigned t = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) { s += f[i] + h[i]; t += u[i]; }
+  for (int i = 0; i < 8; i++) { s += f[i] + h[i] + pk[i].x + pk[i].y; t += u[i]; }
   out[blockIdx.x * blockDim.x + threadIdx.x] = s + (float)t;
 }
 template <int OP> int run(const char *name, float *d) {
@@ -104,6 +112,7 @@ int main() {
   setvbuf(stdout, nullptr, _IONBF, 0);
   float *d; HIPCHECK(hipMalloc(&d, 256 * 1024 * 4));
   run<0>("F  (v_add_f32)", d); run<1>("H  (v_max_f32)", d); run<2>("1F + 1H", d); run<3>("2F + 1H", d); run<4>("3F + 1H", d); run<5>("1F + 2H", d); run<13>("4F + 2H grouped", d);
+  run<60>("PK (v_pk_mul_f32)", d); run<61>("1PK + 1F", d); run<62>("1PK + 2F", d); run<63>("2PK + 2F (six flops)", d); run<64>("6F (the same six flops)", d); run<65>("1PK + 1H", d);
   run<6>("T  (v_rcp_f32)", d); run<7>("1T + 1F", d); run<8>("1T + 3F", d); run<9>("1T + 1H", d);
   run<10>("S  (s_add_u32)", d); run<11>("1S + 1F", d); run<12>("1S + 1H", d);
   run<20>("v_add_f32 sgpr src0 (VOP2)", d); run<34>("v_mul_f32 sgpr src0", d); run<42>("v_subrev_f32 sgpr", d); run<49>("v_add_u32 sgpr", d); run<48>("v_mov_b32 sgpr", d); run<47>("v_mov_b32", d);
