@@ -26,6 +26,21 @@ def test_product_trace_kernels_do_not_spill_and_keep_four_waves(rows):
         assert r["LDS Size [bytes/block]"] <= 160 * 1024, r
 
 
+def test_sgpr_spill_ceiling(rows):
+    """Spilled SGPRs live in VGPR lanes and come back through v_readlane.  On the round-4 builds none of those reloads sits in the
+    traversal step (they are the material tables' buffer descriptors and the fetch code's pointers, read in event passes): the ceiling
+    keeps it that way — a scene-specialised build that spills more than this has started to spill something the step reads."""
+    for r in rows:
+        if not r["name"].startswith("tdt::trace_kernel<false"):
+            continue
+        args = [a.strip() for a in r["name"][len("tdt::trace_kernel<"):-1].split(",")]
+        brick = len(args) >= 8 and args[7] == "true"
+        general = len(args) < 3 or args[2] == "0"
+        if general:
+            continue                                  # (the general kernel: nine memo levels at the register cap; never a bench frame)
+        assert r["SGPRs Spill"] <= (18 if brick else 31), r        # round 4: 15 (unit scenes) / 18 and 25 / 29 / 31
+
+
 def test_every_kernel_fits_the_cu(rows):
     for r in rows:
         assert r["LDS Size [bytes/block]"] <= 160 * 1024, r
