@@ -116,11 +116,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   // round 4's second batch of step slimming (see the uses): the scene-specialised builds; the general kernel, with its nine-level node
   // memo, sits at the register cap and keeps the plain forms
   constexpr bool kSlim2 = DEPTH > 0;
-#ifdef TDT_BRICK_RAND2
-  constexpr bool kSharedRand = true;
-#else
   constexpr bool kSharedRand = !BRICK;                // (scatter<>: one Rand(hit.xy) for metal and dielectric lanes)
-#endif
   __shared__ __attribute__((aligned(16))) uint16_t s_nodes[(BRICK ? kBrickLdsCells : kLdsCells) * 8 + 8];   // + the sentinel slot (BRICK: the host stages no more than fit)
   for (uint32_t i = threadIdx.x * 8u; i < P.lds_nodes; i += (uint32_t)TDT_BLOCK * 8u)      // one cell (8 x u16) per lane and trip
     *reinterpret_cast<uint4 *>(&s_nodes[i]) = *reinterpret_cast<const uint4 *>(&P.packed[i]);
@@ -221,10 +217,6 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   // node loads' latency, not issue slots, bounds a traversal pass and event passes come almost free.  (Round 2, after the
   // traversal step had become cheaper: 0.12 ... 0.35.)
   uint32_t w_steps = 0, w_rays = 0, lane_work = 0;
-#ifdef TDT_SLIM3
-  uint32_t w_steps_acc;
-  asm volatile("s_mov_b32 %0, 0" : "=s"(w_steps_acc));
-#endif
   int threshold = P.event_threshold > 0 ? P.event_threshold : 24;
 
   // region timers of the instrumented build (s_memtime, wave-uniform): 0 traversal step, 1 gate, 2 hit + scatter, 3 end of path,
@@ -306,15 +298,6 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
         float t_enter, t_exit;
         cube_slabs(r, ix, iy, iz, cx, cy, cz, cs, t_stride, t_octree_max, t_enter, t_exit);
         const bool cube_ok = !(t_exit < t_enter);
-#ifdef TDT_SLIM4
-        // (the leaf / empty tail without a branch: selects on the vector unit instead of seven scalar instructions of exec bookkeeping)
-        t_stride = leaf ? t_enter : (cube_ok ? t_exit : t_octree_max);
-        inv_pow_depth = leaf ? cs : inv_pow_depth;
-        if constexpr (BRICK || DEPTH == 0) { if (leaf) owed.set(it > 0, cube_ok); }
-        else owed.bits = leaf ? (it > 0 ? (cube_ok ? 3u : 1u) : 0u) : owed.bits;
-        state = leaf ? ST_HIT : state;
-        it += leaf ? 0 : 1;
-#else
         if (leaf) {
           // CubeHit's record (rc:336-354) is deferred to the event code, where the lanes that hit
           // are batched: only a few lanes per step reach a leaf.  The traversal registers are
@@ -327,7 +310,6 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
           t_stride = cube_ok ? t_exit : t_octree_max;
           it++;
         }
-#endif
       }
       state = (trav && !inside) ? ST_END : state;       // left the octree / ran out of iterations
       // (ONE compare of `state` per pass: who still traverses; whoever left has an event to be served.  A ballot of the step's own conditions
@@ -340,28 +322,14 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     // ------------------------------------------------------------ path events
     TDT_MARK(gate);
     const unsigned long long m_trav = k_trav, m_event = k_event;
-#ifndef TDT_SLIM3
     if (m_trav == 0ull && m_event == 0ull) break;
-#endif
-#ifdef TDT_SLIM3
-    // lanes that take the next traversal step — summed on the scalar unit (asm: the compiler folds a C++ accumulator back into w_steps, which
-    // the vector unit's threshold formula reads, and adds to it with a half-rate VALU instruction every pass); added to w_steps once per event pass
-    { const uint32_t n_ = (uint32_t)__popcll(m_trav); asm volatile("s_add_u32 %0, %0, %1" : "+s"(w_steps_acc) : "s"(n_) : "scc"); }
-#else
     w_steps += (uint32_t)__popcll(m_trav);            // lanes that take the next traversal step
-#endif
     // run the (long, material-divergent) event code only when enough lanes wait for it (a separate
     // threshold for scatter alone was measured: worse at every setting)
     // once the queue has run dry lanes retire (ST_DONE) and only latency is left to win: scale the threshold
     // with the lanes still alive so that the survivors do not wait for company that will never come
     TDT_ST1(STAT_GATE_WAIT_LANES, __popcll(m_event));      // (every pass: lanes parked at the gate or about to be served)
-#ifdef TDT_SLIM3
-    // (the gate on the scalar unit alone: th_now comes out of the event pass as a scalar — one v_readfirstlane per EVENT pass — and "nobody
-    // traverses" is a threshold of zero; the loop's exit test sits behind the event code, the only place a lane can retire)
-    if ((int)__popcll(m_event) < (m_trav != 0ull ? th_now : 0)) { TDT_TICK(1); continue; }
-#else
     if ((int)__popcll(m_event) < th_now && m_trav != 0ull) { TDT_TICK(1); continue; }
-#endif
     TDT_TICK(1);
     TDT_ST(STAT_EVENT_PASS, m_event); TDT_ST(STAT_HIT_PASS, __ballot(state == ST_HIT));
 #ifdef TDT_STATS
@@ -527,9 +495,6 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       state = ST_NEWRAY;
     }
     TDT_MARK(threshold);
-#ifdef TDT_SLIM3
-    w_steps += w_steps_acc; asm volatile("s_mov_b32 %0, 0" : "=s"(w_steps_acc));
-#endif
     w_rays += (uint32_t)__popcll(__ballot(state == ST_NEWRAY));
     if (P.event_threshold <= 0) {
       if (w_rays > kEventWindow) { w_steps >>= 1; w_rays >>= 1; }   // sliding window: the mix of pixels a wave sees changes over a frame
@@ -569,13 +534,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     }
     TDT_TICK(6);
     k_trav = __ballot(state == ST_TRAVERSE); k_event = __ballot(state > ST_TRAVERSE);
-#ifdef TDT_SLIM3
-    if (k_trav == 0ull && k_event == 0ull) break;
-    { const int n_alive = __popcll(k_trav | k_event); const int th_s = __builtin_amdgcn_readfirstlane(threshold);
-      th_now = n_alive == 64 ? th_s : ((th_s * n_alive) >> 6) + 1; }
-#else
     { const int n_alive = __popcll(k_trav | k_event); th_now = n_alive == 64 ? threshold : ((threshold * n_alive) >> 6) + 1; }
-#endif
     TDT_MARK(loop_tail);
   }
   TDT_MARK(after_loop);
