@@ -117,6 +117,11 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   // memo, sits at the register cap and keeps the plain forms
   constexpr bool kSlim2 = DEPTH > 0;
   constexpr bool kSharedRand = !BRICK;                // (scatter<>: one Rand(hit.xy) for metal and dielectric lanes)
+#ifdef TDT_NO_SHARED_NORM
+  constexpr bool kSharedNorm = false;
+#else
+  constexpr bool kSharedNorm = kSlim2;                // (scatter<>: one normalize() behind the three material branches)
+#endif
   __shared__ __attribute__((aligned(16))) uint16_t s_nodes[(BRICK ? kBrickLdsCells : kLdsCells) * 8 + 8];   // + the sentinel slot (BRICK: the host stages no more than fit)
   for (uint32_t i = threadIdx.x * 8u; i < P.lds_nodes; i += (uint32_t)TDT_BLOCK * 8u)      // one cell (8 x u16) per lane and trip
     *reinterpret_cast<uint4 *>(&s_nodes[i]) = *reinterpret_cast<const uint4 *>(&P.packed[i]);
@@ -217,6 +222,9 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   // node loads' latency, not issue slots, bounds a traversal pass and event passes come almost free.  (Round 2, after the
   // traversal step had become cheaper: 0.12 ... 0.35.)
   uint32_t w_steps = 0, w_rays = 0, lane_work = 0;
+#ifdef TDT_THRESHOLD_EVERY
+  uint32_t ev_no = 0;
+#endif
   int threshold = P.event_threshold > 0 ? P.event_threshold : 24;
 
   // region timers of the instrumented build (s_memtime, wave-uniform): 0 traversal step, 1 gate, 2 hit + scatter, 3 end of path,
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       h.px = src.px; h.py = src.py; h.pz = src.pz; h.nx = src.nx; h.ny = src.ny; h.nz = src.nz; h.ff = src.ff;
       h.index = hit_index;
       Ray nr; float tr, tg, tb;
-      const bool scattered = scatter<COUNT, kSharedRand>(ms, r, h, mat, nr, tr, tg, tb, cnt);
+      const bool scattered = scatter<COUNT, kSharedRand, kSharedNorm>(ms, r, h, mat, nr, tr, tg, tb, cnt);
       TDT_MARK(hit_epilogue);
       if (scattered) {
         ar = ar * tr; ag = ag * tg; ab = ab * tb;
@@ -496,7 +504,11 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     }
     TDT_MARK(threshold);
     w_rays += (uint32_t)__popcll(__ballot(state == ST_NEWRAY));
+#ifdef TDT_THRESHOLD_EVERY
+    if (P.event_threshold <= 0 && (ev_no++ & (uint32_t)(TDT_THRESHOLD_EVERY - 1)) == 0u) {
+#else
     if (P.event_threshold <= 0) {
+#endif
       if (w_rays > kEventWindow) { w_steps >>= 1; w_rays >>= 1; }   // sliding window: the mix of pixels a wave sees changes over a frame
       // (a schedule, not arithmetic of the image: the raw hardware rcp / sqrt do, 3 instructions instead of ~35)
       const float est = 64.0f * __builtin_amdgcn_rcpf(0.5f + __builtin_amdgcn_sqrtf(P.event_k * (float)w_steps * __builtin_amdgcn_rcpf((float)w_rays + 1.0f)));

@@ -801,7 +801,7 @@ TDT_DEV void unit_or_normalised(float nx, float ny, float nz, float &mx, float &
 // switch (materials[hit.index].type) rc:278-291; returns false when the path ends
 // SHARED_RAND: Rand(hit.point.xy) is the first draw of BOTH ScatterMetal (rc:488 via RandVec3) and ScatterDielectric (rc:513) — one evaluation
 // for the lanes of either kind (bench frame -1.2 %; the brick builds, at the edge of their register budget, lose 0.5 % to it and keep two)
-template <bool COUNT, bool SHARED_RAND = false>
+template <bool COUNT, bool SHARED_RAND = false, bool SHARED_NORM = false>
 TDT_DEV bool scatter(const MatSource &ms, const Ray &r, const Hit &h, const MatRef &mat, Ray &out, float &ar, float &ag, float &ab, Counters &cnt) {
   const int32_t type = (int32_t)mat.type;
   // the second-level reads, all of them, before the switch (see MatSource); used at the end of the branches
@@ -814,6 +814,7 @@ TDT_DEV bool scatter(const MatSource &ms, const Ray &r, const Hit &h, const MatR
   if (COUNT) { cnt.lambertian += (type == 0); cnt.metal += (type == 1); cnt.dielectric += (type == 2); cnt.unknown += ((uint32_t)type > 2u); }
   float rnd_md = 0.0f;
   if (SHARED_RAND && (type == 1 || type == 2)) rnd_md = rand2(h.px, h.py);
+  float ux = 1.0f, uy = 0.0f, uz = 0.0f;              // SHARED_NORM: the scattered direction before normalize()
   if (type == 0) {   // ScatterLambertian rc:470-482, constructFrisvad rc:453-468, SampleGGXVNDF rc:27-49
     TDT_MARK(lambert);
     float mx, my, mz; float rs;
@@ -866,10 +867,9 @@ TDT_DEV bool scatter(const MatSource &ms, const Ray &r, const Hit &h, const MatR
     ex = ex * rs; ey = ey * rs; ez = ez * rs;
     float dt = ((ez * dz + ey * dy) + ex * dx) * 2.0f;
     float qx = nx + (dx + -(dt * ex)), qy = ny + (dy + -(dt * ey)), qz = nz + (dz + -(dt * ez));
-    rs = q_rsq((qz * qz + qy * qy) + qx * qx);
-    out.dx = qx * rs; out.dy = qy * rs; out.dz = qz * rs;
     ar = alb_r; ag = alb_g; ab = alb_b;
-    return true;
+    if (!SHARED_NORM) { rs = q_rsq((qz * qz + qy * qy) + qx * qx); out.dx = qx * rs; out.dy = qy * rs; out.dz = qz * rs; return true; }
+    ux = qx; uy = qy; uz = qz;
   }
   if (type == 1) {   // ScatterMetal rc:484-491, RandInHemisphere rc:106-115 (one cube sample, as compiled)
     TDT_MARK(metal);
@@ -884,11 +884,14 @@ TDT_DEV bool scatter(const MatSource &ms, const Ray &r, const Hit &h, const MatR
     bool same = -(hz * nz + hy * ny) < hx * nx;
     if (!same) { hx = -hx; hy = -hy; hz = -hz; }
     float qx = rx + fuzz * hx, qy = ry + fuzz * hy, qz = rz + fuzz * hz;
-    rs = q_rsq((qz * qz + qy * qy) + qx * qx);
-    qx = qx * rs; qy = qy * rs; qz = qz * rs;
-    out.dx = qx; out.dy = qy; out.dz = qz;
     ar = alb_r; ag = alb_g; ab = alb_b;
-    return -(qz * nz + qy * ny) < qx * nx;
+    if (!SHARED_NORM) {
+      rs = q_rsq((qz * qz + qy * qy) + qx * qx);
+      qx = qx * rs; qy = qy * rs; qz = qz * rs;
+      out.dx = qx; out.dy = qy; out.dz = qz;
+      return -(qz * nz + qy * ny) < qx * nx;
+    }
+    ux = qx; uy = qy; uz = qz;
   }
   if (type == 2) {   // ScatterDielectric rc:499-522, reflectance rc:494-497
     TDT_MARK(dielectric);
@@ -913,12 +916,18 @@ TDT_DEV bool scatter(const MatSource &ms, const Ray &r, const Hit &h, const MatR
         ox_ = ratio * dx + -(m * nx); oy_ = ratio * dy + -(m * ny); oz_ = ratio * dz + -(m * nz);
       } else { ox_ = 0.0f; oy_ = 0.0f; oz_ = 0.0f; }
     }
-    float rs = q_rsq((oz_ * oz_ + oy_ * oy_) + ox_ * ox_);
-    out.dx = ox_ * rs; out.dy = oy_ * rs; out.dz = oz_ * rs;
     ar = 1.0f; ag = 1.0f; ab = 1.0f;
-    return true;
+    if (!SHARED_NORM) { float rs = q_rsq((oz_ * oz_ + oy_ * oy_) + ox_ * ox_); out.dx = ox_ * rs; out.dy = oy_ * rs; out.dz = oz_ * rs; return true; }
+    ux = ox_; uy = oy_; uz = oz_;
   }
-  return false;
+  if (!SHARED_NORM || (uint32_t)type > 2u) return false;
+  // normalize(...) — the last operation of all three scatter functions (rc:481, rc:489, rc:521), in the same association — once, for
+  // the lanes of every material, behind the branches: three transcendentals + 16 other instructions that each branch used to issue for
+  // its own few lanes.  ScatterMetal's test of the normalised direction against the normal (rc:490) follows it.
+  const float rs = q_rsq((uz * uz + uy * uy) + ux * ux);
+  ux = ux * rs; uy = uy * rs; uz = uz * rs;
+  out.dx = ux; out.dy = uy; out.dz = uz;
+  return type != 1 || -(uz * nz + uy * ny) < ux * nx;
 }
 
 // primary ray of sample s at pixel (px,py): rc:240-245, CameraGetRay rc:304-307
