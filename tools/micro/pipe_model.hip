@@ -44,6 +44,18 @@ __global__ __launch_bounds__(1024) void k(float *out, int iters, float fs) {
         if (OP == 63) { PK(i); F(i); PK((i + 3) & 7); FM(i); }        // 2 PK + 2 F: six flops
         if (OP == 64) { F(i); FM(i); F((i + 1) & 7); FM((i + 1) & 7); F((i + 2) & 7); FM((i + 2) & 7); }   // 6 F: the same six flops
         if (OP == 65) { PK(i); H(i); }
+        // ---- which half-rate kinds hide a full-rate instruction the way v_max does ----
+        if (OP == 70) { F(i); asm volatile("v_add_f32 %0, s20, %0" : "+v"(h[i]) :: "s20"); }            // 1 F + 1 add with an SGPR operand
+        if (OP == 71) { F(i); FM(i); asm volatile("v_add_f32 %0, s20, %0" : "+v"(h[i]) :: "s20"); }     // 2 F + 1 ...
+        if (OP == 72) asm volatile("v_mul_f32 %0, 0x3f8020c5, %0" : "+v"(f[i]));                         // 32-bit literal operand
+        if (OP == 73) { F(i); asm volatile("v_mul_f32 %0, 0x3f8020c5, %0" : "+v"(h[i])); }
+        if (OP == 74) { F(i); asm volatile("v_cvt_f32_u32 %0, %1" : "=v"(h[i]) : "v"(u[i])); }
+        if (OP == 75) { F(i); asm volatile("v_cmp_lt_f32 s[20:21], %0, %1" :: "v"(h[i]), "v"(b) : "s20", "s21"); }
+        if (OP == 76) { F(i); asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7])); }
+        if (OP == 77) { F(i); H(i); FM(i); H((i + 3) & 7); F((i + 5) & 7); H((i + 6) & 7); }             // 3 F + 3 H alternating
+        if (OP == 78) { F(i); FM(i); H(i); F((i + 3) & 7); FM((i + 3) & 7); H((i + 3) & 7); F((i + 5) & 7); FM((i + 5) & 7); H((i + 6) & 7); }   // 6 F + 3 H
+        if (OP == 79) { F(i); FM(i); F((i + 3) & 7); FM((i + 3) & 7); F((i + 5) & 7); FM((i + 5) & 7); asm volatile("v_add_f32 %0, s20, %0" : "+v"(h[i]) :: "s20"); asm volatile("v_add_f32 %0, s20, %0" : "+v"(h[(i + 3) & 7]) :: "s20"); asm volatile("v_add_f32 %0, s20, %0" : "+v"(h[(i + 6) & 7]) :: "s20"); }   // 6 F + 3 SGPR-operand adds
+        if (OP == 80) { F(i); FM(i); F((i + 3) & 7); FM((i + 3) & 7); F((i + 5) & 7); FM((i + 5) & 7); F((i + 1) & 7); FM((i + 2) & 7); F((i + 6) & 7); }   // 9 F: the same nine flops
         if (OP == 13) { F(i); F((i + 1) & 7); F((i + 2) & 7); F((i + 3) & 7); H(i); H((i + 4) & 7); }   // 4 F + 2 H, grouped
         // ---- classes of single instructions ----
         if (OP == 20) asm volatile("v_add_f32 %0, s20, %0" : "+v"(f[i]) :: "s20");                     // VOP2, SGPR src0
@@ -115,6 +127,9 @@ int main() {
   run<60>("PK (v_pk_mul_f32)", d); run<61>("1PK + 1F", d); run<62>("1PK + 2F", d); run<63>("2PK + 2F (six flops)", d); run<64>("6F (the same six flops)", d); run<65>("1PK + 1H", d);
   run<6>("T  (v_rcp_f32)", d); run<7>("1T + 1F", d); run<8>("1T + 3F", d); run<9>("1T + 1H", d);
   run<10>("S  (s_add_u32)", d); run<11>("1S + 1F", d); run<12>("1S + 1H", d);
+  run<70>("1F + 1 sgpr-operand add", d); run<71>("2F + 1 sgpr-operand add", d); run<72>("v_mul_f32 literal", d); run<73>("1F + 1 literal mul", d);
+  run<74>("1F + 1 cvt", d); run<75>("1F + 1 cmp", d); run<76>("1F + 1 lshl_or", d); run<77>("3F + 3H alternating", d); run<78>("6F + 3H", d);
+  run<79>("6F + 3 sgpr-operand adds", d); run<80>("9F", d);
   run<20>("v_add_f32 sgpr src0 (VOP2)", d); run<34>("v_mul_f32 sgpr src0", d); run<42>("v_subrev_f32 sgpr", d); run<49>("v_add_u32 sgpr", d); run<48>("v_mov_b32 sgpr", d); run<47>("v_mov_b32", d);
   run<21>("v_or_b32", d); run<22>("v_xor_b32", d); run<23>("v_sub_u32", d); run<24>("v_mul_u32_u24", d); run<25>("v_mad_u32_u24", d); run<36>("v_mul_lo_u32", d);
   run<26>("v_fmac_f32", d); run<35>("v_fma_f32 inline const", d); run<27>("v_rndne_f32", d); run<28>("v_trunc_f32", d); run<29>("v_cvt_i32_f32", d); run<39>("v_cvt_f32_i32", d); run<54>("v_cvt_f32_ubyte0", d);
