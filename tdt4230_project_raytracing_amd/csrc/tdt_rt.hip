@@ -361,7 +361,6 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     else lane_work += (state > ST_TRAVERSE) ? kCostEvent : 0u;
     if (COUNT) lane_E += (state > ST_TRAVERSE) ? 1u : 0u;
     if (state == ST_HIT) {                            // RayColor loop body rc:272-295
-      lane_work |= kCostHitFlag;                      // (the pixel hit something: see thin_key)
       if (COUNT) { cnt.scatter_slots += slot64(); cnt.scatter_active++; }
       const MatRef mat = material_fetch(ms, hit_index);
       TDT_ST(STAT_LAMB_PASS, __ballot(mat.type == 0u)); TDT_ST(STAT_METAL_PASS, __ballot(mat.type == 1u)); TDT_ST(STAT_DIEL_PASS, __ballot(mat.type == 2u));
@@ -1069,11 +1068,6 @@ __device__ __forceinline__ uint32_t run_cost(uint32_t c) {          // wave-wide
 // towards the mean of its 8x8 tile — neighbours see the same surfaces, so their 64 x more samples say more about what this
 // pixel's remaining samples will cost than its own few do.  What it buys is the END of the frame: a pixel whose probe samples
 // happened to be cheap no longer starts last and finishes alone (probe order: the last wave ended 8 % after the first).
-// the cost words: bits 0-30 the cost (sums saturate), bit 31 "a path of this pixel hit something" (kCostHitFlag)
-__device__ __forceinline__ uint32_t cost_add(uint32_t before, uint32_t c) {
-  const uint32_t s = (before & ~kCostHitFlag) + (c & ~kCostHitFlag);
-  return (s > ~kCostHitFlag ? ~kCostHitFlag : s) | ((before | c) & kCostHitFlag);
-}
 __device__ __forceinline__ uint32_t blended_cost(uint32_t a, float blend) {
   // (blend < 0: experiment — shrink towards the tile's MAXIMUM instead of its mean, weight |blend|)
   float tile_stat;
@@ -1086,27 +1080,7 @@ __device__ __forceinline__ uint32_t blended_cost(uint32_t a, float blend) {
   const float v = (1.0f - blend) * (float)a + blend * tile_stat;
   return a == 0u ? 0u : (uint32_t)(v < 1.0f ? 1.0f : (v > 4.0e9f ? 4.0e9f : v));     // (0 = never run: stays last)
 }
-// The key of a pixel whose history is THIN (the probe of a two-phase frame): two classes.  What a pixel's remaining samples cost is
-// predictable from a few of them as long as its rays hit nothing (sky, or the empty part of a sparse tree: however many steps, every
-// sample takes them again); where paths hit and scatter, a later sample can cost 50 x what the probe saw (1080p / 512^3: a scattered
-// ray that starts at a stale hit record runs to max_iter, sample after sample, from some sample on; the pixels it happens to are not
-// told apart by anything the probe measures).  A late start is what makes such a pixel the frame's tail, so every pixel of an 8x8 tile
-// in which ANY probe path hit something goes before all pixels of tiles where none did, each class in descending (blended) cost order:
-// the surprises happen while there is still work to hide them behind, and the frame ends on pixels whose cost is known.  (Model:
-// tools/sim/order_sim.py on per-pixel costs dumped from the GPU — main launch 1.31 -> 1.05 x the ideal makespan on the 512^3 frame,
-// 1.05 -> 1.02 on the bench frame.)  Both classes share the 512 bins: 256 each, 16 per octave from cost 2^6 up.
-__device__ __forceinline__ uint32_t thin_key(uint32_t a, float blend, uint32_t g, int classes) {
-  const uint32_t last = (32u << g) - 1u;
-  const bool risky = classes && __ballot((a & kCostHitFlag) != 0u) != 0ull;      // (a wave = 64 consecutive slots = one 8x8 tile, as in run_cost)
-  const uint32_t c = blended_cost(a & ~kCostHitFlag, blend);
-  if (c == 0u) return last;
-  const uint32_t e = 31u - (uint32_t)__builtin_clz(c);
-  const uint32_t frac = e >= g ? (c >> (e - g)) & ((1u << g) - 1u) : (c << (g - e)) & ((1u << g) - 1u);
-  const uint32_t idx = (e << g) + frac, base = 6u << g, half = 16u << g;
-  const uint32_t idx2 = idx < base ? 0u : (idx - base >= half ? half - 1u : idx - base);
-  return last - ((risky ? half : 0u) + idx2);
-}
-__global__ __launch_bounds__(1024) void order_hist_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ acc, uint32_t n, uint32_t *__restrict__ hist, uint32_t g, int smooth, int keep, float blend, int classes) {
+__global__ __launch_bounds__(1024) void order_hist_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ acc, uint32_t n, uint32_t *__restrict__ hist, uint32_t g, int smooth, int keep, float blend) {
   __shared__ uint32_t s_bin[512];
   if (threadIdx.x < 512) s_bin[threadIdx.x] = 0;
   __syncthreads();
@@ -1114,23 +1088,23 @@ __global__ __launch_bounds__(1024) void order_hist_kernel(const uint32_t *__rest
   for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) {
     // acc = the cost estimate the order is built from: this dispatch's costs, added to those of the earlier dispatches
     // that traced the same inputs (keep) — every pass sharpens the estimate — or on their own
-    const uint32_t c = cost[i], before = keep ? acc[i] : 0u, a = cost_add(before, c);
+    const uint32_t c = cost[i], before = keep ? acc[i] : 0u, a = before + c < before ? 0xFFFFFFFFu : before + c;
     acc[i] = a;
-    if (smooth) { const uint32_t k = order_key(run_cost(a & ~kCostHitFlag), g); if ((threadIdx.x & 63u) == 0) atomicAdd(&s_bin[k], 64u); }
-    else atomicAdd(&s_bin[blend != 0.0f ? thin_key(a, blend, g, classes) : order_key(a & ~kCostHitFlag, g)], 1u);
+    if (smooth) { const uint32_t k = order_key(run_cost(a), g); if ((threadIdx.x & 63u) == 0) atomicAdd(&s_bin[k], 64u); }
+    else atomicAdd(&s_bin[order_key(blend != 0.0f ? blended_cost(a, blend) : a, g)], 1u);
   }
   __syncthreads();
   if (threadIdx.x < 512 && s_bin[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_bin[threadIdx.x]);
 }
 __global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restrict__ cost, uint32_t *__restrict__ acc, uint32_t n, const uint32_t *__restrict__ prefix,
-                                                             uint32_t *__restrict__ cursor, uint32_t *__restrict__ order, uint32_t g, int smooth, float blend, int classes) {
+                                                             uint32_t *__restrict__ cursor, uint32_t *__restrict__ order, uint32_t g, int smooth, float blend) {
   __shared__ uint32_t s_bin[512], s_base[512];
   if (threadIdx.x < 512) s_bin[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t lo = blockIdx.x * kOrderChunk, hi = lo + kOrderChunk < n ? lo + kOrderChunk : n;
   for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) {
-    if (smooth) { const uint32_t k = order_key(run_cost(acc[i] & ~kCostHitFlag), g); if ((threadIdx.x & 63u) == 0) atomicAdd(&s_bin[k], 64u); }
-    else atomicAdd(&s_bin[blend != 0.0f ? thin_key(acc[i], blend, g, classes) : order_key(acc[i] & ~kCostHitFlag, g)], 1u);
+    if (smooth) { const uint32_t k = order_key(run_cost(acc[i]), g); if ((threadIdx.x & 63u) == 0) atomicAdd(&s_bin[k], 64u); }
+    else atomicAdd(&s_bin[order_key(blend != 0.0f ? blended_cost(acc[i], blend) : acc[i], g)], 1u);
   }
   __syncthreads();
   if (threadIdx.x < 512) {
@@ -1140,13 +1114,13 @@ __global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restric
   __syncthreads();
   for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) {
     if (smooth) {
-      const uint32_t k = order_key(run_cost(acc[i] & ~kCostHitFlag), g);
+      const uint32_t k = order_key(run_cost(acc[i]), g);
       uint32_t pos = 0;
       if ((threadIdx.x & 63u) == 0) pos = atomicAdd(&s_base[k], 64u);
       pos = (uint32_t)__shfl((int)pos, 0, 64);
       order[pos + (threadIdx.x & 63u)] = i;
     } else {
-      order[atomicAdd(&s_base[blend != 0.0f ? thin_key(acc[i], blend, g, classes) : order_key(acc[i] & ~kCostHitFlag, g)], 1u)] = i;
+      order[atomicAdd(&s_base[order_key(blend != 0.0f ? blended_cost(acc[i], blend) : acc[i], g)], 1u)] = i;
     }
     cost[i] = 0;
     // tile-sum mode = the inputs changed: these costs served once, as a prior for this dispatch's order; the estimate for
@@ -1164,15 +1138,8 @@ __global__ __launch_bounds__(1024) void order_scatter_kernel(uint32_t *__restric
 // drawn the line at 0.25, between the 4K/256^3 and the 1080p/512^3 frames it was fitted on; re-measured in round 2 on the
 // three bench frames, batches win or tie on all of them (1080p/64^3, f = 0.3: 24.8 -> 20.9 ms history-free; 1080p/512^3:
 // 158 -> 155 ms history-free, 125.7 -> 126.9 replay), and no frame in the repository reaches f = 1.
-__device__ __forceinline__ float bin_cost(uint32_t k, uint32_t g, int two_class) {     // the cost a bin of order_key / thin_key stands for
-  const uint32_t bins = 32u << g;
-  uint32_t idx = (bins - 1u) - k;
-  if (two_class) idx = (idx & ((16u << g) - 1u)) + (6u << g);
-  const uint32_t e = idx >> g, frac = idx & ((1u << g) - 1u);
-  return __builtin_ldexpf(1.0f + (float)frac / (float)(1u << g), (int)e);
-}
 __global__ __launch_bounds__(512) void order_plan_kernel(const uint32_t *__restrict__ hist, uint32_t g, uint32_t lanes, float max_share,
-                                                         uint32_t *__restrict__ plan, int smooth, uint32_t *__restrict__ next_set, uint32_t *__restrict__ prefix, int two_class) {
+                                                         uint32_t *__restrict__ plan, int smooth, uint32_t *__restrict__ next_set, uint32_t *__restrict__ prefix) {
   // the counters of the NEXT order pass (it alternates between two sets): zeroed here, one launch instead of a memset per frame
   next_set[threadIdx.x] = 0u; next_set[512 + threadIdx.x] = 0u;
   __shared__ float s_sum[512];
@@ -1180,7 +1147,8 @@ __global__ __launch_bounds__(512) void order_plan_kernel(const uint32_t *__restr
   const uint32_t bins = 32u << g, k = threadIdx.x;
   float rep = 0.f; uint32_t cnt = 0;
   if (k < bins - 1u) {                                // the last bin holds the never-run slots (cost 0)
-    rep = bin_cost(k, g, two_class);
+    const uint32_t idx = (bins - 1u) - k, e = idx >> g, frac = idx & ((1u << g) - 1u);
+    rep = __builtin_ldexpf(1.0f + (float)frac / (float)(1u << g), (int)e);
     cnt = hist[k];
   }
   s_sum[k] = rep * (float)cnt; s_cnt[k] = cnt;
@@ -1202,7 +1170,8 @@ __global__ __launch_bounds__(512) void order_plan_kernel(const uint32_t *__restr
   const uint32_t want = n / 1000u + 1u;
   // the first bin (in descending cost order) at which the running count reaches the 99.9th percentile
   if (s_cnt[k] >= want && (k == 0u || s_cnt[k - 1u] < want)) {
-    const float c_hi = bin_cost(k, g, two_class);
+    const uint32_t idx = (bins - 1u) - k, e = idx >> g, frac = idx & ((1u << g) - 1u);
+    const float c_hi = __builtin_ldexpf(1.0f + (float)frac / (float)(1u << g), (int)e);
     plan[0] = (total > 0.f && c_hi * (float)lanes > max_share * total) ? 1u : 0u;
   }
 }
@@ -1515,21 +1484,20 @@ int launch(tdt_compute *c, int width, int height, int depth, int mode, int spp_b
         // shrunk towards the 8x8-tile mean (blended_cost)
         ctx->acc_samples = (keep_costs ? ctx->acc_samples : 0u) + ctx->last_launch_samples;
         const float blend = (!smooth && ctx->acc_samples < 16u) ? ctx->order_blend : 0.0f;
-        static const int classes = getenv("TDT_NO_HIT_CLASS") ? 0 : 1;      // (thin_key: tiles in which a probe path hit something first)
         if (smooth) ctx->acc_samples = 0;               // (tile-sum mode drops the sums after use: order_scatter_kernel)
         const uint32_t n_slots = (uint32_t)t.owned * 1024u, n_chunks = (n_slots + tdt::kOrderChunk - 1) / tdt::kOrderChunk;
         const uint32_t og = tdt::kOrderBits;
         // two sets of sort counters alternate: the plan kernel of this pass zeroes the set of the next one
         uint32_t *hist = ctx->order_hist + 1024u * ctx->order_parity, *hist_next = ctx->order_hist + 1024u * (ctx->order_parity ^ 1u), *plan = ctx->order_hist + 2048;
-        hipLaunchKernelGGL(tdt::order_hist_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, ctx->slot_acc, n_slots, hist, og, smooth, keep_costs ? 1 : 0, blend, classes);
+        hipLaunchKernelGGL(tdt::order_hist_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, ctx->slot_acc, n_slots, hist, og, smooth, keep_costs ? 1 : 0, blend);
         {
           const float max_share = ctx->max_share;
           const uint32_t lanes = (uint32_t)ctx->num_cus * TDT_BLOCKS_PER_CU * TDT_BLOCK;
-          hipLaunchKernelGGL(tdt::order_plan_kernel, dim3(1), dim3(512), 0, ctx->stream, hist, og, lanes, max_share, plan, smooth, hist_next, plan + 4, (!smooth && blend != 0.0f && classes) ? 1 : 0);
+          hipLaunchKernelGGL(tdt::order_plan_kernel, dim3(1), dim3(512), 0, ctx->stream, hist, og, lanes, max_share, plan, smooth, hist_next, plan + 4);
           P.plan = plan;
         }
         hipLaunchKernelGGL(tdt::order_scatter_kernel, dim3(n_chunks), dim3(1024), 0, ctx->stream, ctx->slot_cost, ctx->slot_acc, n_slots,
-                           plan + 4, hist + 512, ctx->slot_order, og, smooth, blend, classes);
+                           plan + 4, hist + 512, ctx->slot_order, og, smooth, blend);
         {
           const hipError_t e = hipGetLastError();
           if (e != hipSuccess) {
@@ -2134,14 +2102,7 @@ static int dispatch_frame(tdt_compute *c, int width, int height, int depth) {
       const int probe = spp / ctx->probe_div >= 1 ? spp / ctx->probe_div : 1;        // spp/16; measured: 1/8 and 1/32 are 0-3 % slower, 1/64 5 % (TDT_PROBE_DIV)
       ctx->probe_launch = true;
       phase_mark(ctx, 0);
-      // (experiment, TDT_PREPROBE=n: the probe itself in two launches — n samples in image order, the rest of the probe in the order those
-      // n samples give: the probe's own tail is that of a launch in image order, a heavy pixel started late)
-      static const int preprobe = getenv("TDT_PREPROBE") ? atoi(getenv("TDT_PREPROBE")) : 0;
-      int rc = TDT_OK;
-      if (preprobe > 0 && preprobe < probe) {
-        rc = launch(c, width, height, depth, 1, 0, preprobe, ctx->frame_carry, 0, nullptr);
-        if (rc == TDT_OK) rc = launch(c, width, height, depth, 1, preprobe, probe - preprobe, ctx->frame_carry, 0, nullptr);
-      } else rc = launch(c, width, height, depth, 1, 0, probe, ctx->frame_carry, 0, nullptr);
+      int rc = launch(c, width, height, depth, 1, 0, probe, ctx->frame_carry, 0, nullptr);
       ctx->probe_launch = false;
       phase_mark(ctx, 1);
       ctx->carry_final = true;                       // 64 B per pixel that the resolve does not read: not written

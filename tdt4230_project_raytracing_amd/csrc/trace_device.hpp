@@ -483,7 +483,6 @@ TDT_DEV void build_top_grid(const uint16_t *lds, uint32_t lds_nodes, int depth, 
 // a pixel's cost for the hand-out order of the next dispatch (tdt_rt.hip, "Cost-feedback scheduling"):
 // tree levels visited + kCostStep per traversal step + kCostEvent per path event (measured plateau 24..128)
 constexpr uint32_t kCostStep = 3, kCostEvent = 64, kCostRayStep = 7;      // (kCostRayStep: per step when the levels are not counted — 3 + the ~4 levels a step used to visit)
-constexpr uint32_t kCostHitFlag = 0x80000000u;   // bit 31 of a pixel's cost word: one of its paths hit something (thin_key, tdt_rt.hip)
 constexpr uint32_t kEventWindow = 1024;   // rays after which the adaptive event threshold's running counts are halved
 constexpr int kMemoLevels = 9;
 constexpr int kBrickMemoLevels = 3;   // BRICK builds (see trace_kernel): >= 2, the levels their jump covers beyond kMemoFirst
