@@ -122,6 +122,11 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
   constexpr uint32_t kThresholdEvery = kSlim2 ? 8u : 1u;      // (a power of two; see the threshold update.  The general kernel has no register for the counter)
 #endif
   constexpr bool kSharedRand = !BRICK;                // (scatter<>: one Rand(hit.xy) for metal and dielectric lanes)
+#ifdef TDT_NO_STUCK_CUT
+  constexpr bool kStuckCut = false;
+#else
+  constexpr bool kStuckCut = BRICK && !COUNT;         // (rays that stop advancing leave the traversal loop at once: see the step's tail)
+#endif
 #ifdef TDT_NO_SHARED_NORM
   constexpr bool kSharedNorm = false;
 #else
@@ -295,6 +300,7 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
       if (inside) {
         float ugx, ugy, ugz; uint32_t value;
         if (COUNT) cnt.iterations++;
+        const float ipd_in = inv_pow_depth;          // (kStuckCut)
         const bool leaf = POW2 ? tree_lookup_pow2<COUNT, kMemo, DEPTH, RESIDENT, SAFEV, FULL, BRICK, TABLE>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, memo, cnt)
                                : tree_lookup<COUNT>(P, ns, lx, ly, lz, inv_pow_depth, ugx, ugy, ugz, value, cnt);
         TDT_MARK(traversal_b);
@@ -321,7 +327,17 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
           owed.set(it > 0, cube_ok);
           state = ST_HIT;
         } else {
-          t_stride = cube_ok ? t_exit : t_octree_max;
+          const float ts_new = cube_ok ? t_exit : t_octree_max;
+          if (kStuckCut) {
+            // A step that leaves (t_stride, inv_pow_depth) as it found them will find them so again: the loop body is a function of these two
+            // and of the ray, so every remaining iteration up to max_iter repeats this one and OctreeHit returns false (rc:449).  It happens:
+            // at the finest levels of a 256^3 / 512^3 tree treeLookup's float index arithmetic (rc:376-378) hands back a cell the sample
+            // point is not in, whose slab interval along the ray is empty at t_stride — 54 % of all iterations of the 4K/256^3 frame and
+            // 86 % of the 1080p/512^3 frame are such repeats (counted with the oracle; the sums with and without them are the same bits).
+            // The lane leaves the loop the way the last iteration would: nothing but `false` comes out of it.
+            const bool stuck = __float_as_uint(ts_new) == __float_as_uint(t_stride) && __float_as_uint(inv_pow_depth) == __float_as_uint(ipd_in);
+            t_stride = stuck ? t_octree_max : ts_new;
+          } else t_stride = ts_new;
           it++;
         }
       }
