@@ -125,7 +125,10 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
 #ifdef TDT_NO_STUCK_CUT
   constexpr bool kStuckCut = false;
 #else
-  constexpr bool kStuckCut = BRICK && !COUNT;         // (rays that stop advancing leave the traversal loop at once: see the step's tail)
+  // (rays that stop advancing leave the traversal loop at once: see the step's tail.  The brick builds = trees of depth 6-9 outside the LDS
+  // table, where it was found and measured; in every build of depth >= 7 it costs the demo frame and the monument 0.5-1 % and wins nothing
+  // on the held-out set)
+  constexpr bool kStuckCut = BRICK && !COUNT;
 #endif
 #ifdef TDT_NO_SHARED_NORM
   constexpr bool kSharedNorm = false;

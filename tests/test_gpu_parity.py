@@ -158,3 +158,31 @@ def test_octree_scale_other_than_one(oracle, cfg, scale):
         r.close()
     assert _bits_equal(first, ref).all() and _bits_equal(again, ref).all()
     assert (ref[..., :3] != ref[0, 0, :3]).any()                       # the scene is in view
+
+
+@pytest.mark.parametrize("cfg,max_iter", [(5, None), (3, None), (5, 40), (3, 1000)])
+def test_rays_that_stop_advancing_leave_the_loop_with_the_same_bits(oracle, monkeypatch, cfg, max_iter):
+    """OctreeHit's loop (raytracer.comp:410-447) is a function of (t_stride, inv_pow_depth) and the ray.  At the finest levels of the
+    256^3 / 512^3 trees treeLookup's float index arithmetic (rc:376-378) can hand back a cell the sample point is not in, whose slab
+    interval along the ray is empty at t_stride: the step leaves both unchanged, and so does every later one until max_iter — more than
+    half of all iterations of these frames (the oracle's own count below: 20-70 iterations per OctreeHit call where a 64^3 tree takes
+    nine).  The brick builds end such a lane's loop at the first repeat; the walk build (TDT_NO_BRICKS) runs every iteration.  Both
+    are the oracle's bits, whatever max_iter is (a stuck ray ends as `false` either way; a ray that merely runs out of iterations is not
+    touched), in a two-phase frame and in its replay."""
+    scene = host.Scene.config(cfg)
+    if max_iter is not None:
+        oi = scene.blobs[7].copy(); oi[1] = max_iter; scene.blobs[7] = oi
+    cam = host.camera_reference_pose(192, 112, 16, 8)
+    ref, st = oracle.render(scene, cam, threads=8, want_stats=True)
+    if max_iter is None:
+        assert st["iterations"] > 15 * st["octree_hit_calls"], st       # the premise: this frame is full of rays that stop advancing (64^3: 9 per call)
+    for walk in (False, True):
+        if walk:
+            monkeypatch.setenv("TDT_NO_BRICKS", "1")
+        r = rt.Renderer(scene, cam)
+        try:
+            for _ in range(2):
+                assert _bits_equal(r.render(), ref).all()
+            assert r.ctx.last_variant()["brick"] == (0 if walk else 1)
+        finally:
+            r.close()
