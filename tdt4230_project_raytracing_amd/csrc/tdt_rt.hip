@@ -121,7 +121,8 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
 #else
   constexpr uint32_t kThresholdEvery = kSlim2 ? 8u : 1u;      // (a power of two; see the threshold update.  The general kernel has no register for the counter)
 #endif
-  constexpr bool kSharedRand = !BRICK;                // (scatter<>: one Rand(hit.xy) for metal and dielectric lanes)
+  constexpr bool kSharedRand = !BRICK;                // (scatter<>: one Rand(hit.xy) for metal and dielectric lanes; in the brick builds -0.8 % on 4K/256^3 on its own, +0.6 % on 512^3 together with kColdArgs: not there)
+  constexpr bool kColdArgs = BRICK;                   // (see material_source's use)
 #ifdef TDT_NO_STUCK_CUT
   constexpr bool kStuckCut = false;
 #else
@@ -178,7 +179,14 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     ns.bricks = reinterpret_cast<const void *>(((uintptr_t)hi << 32) | (uintptr_t)lo);
   }
   ns.cells = __builtin_amdgcn_make_buffer_rsrc((void *)P.cells, 0, (int)((P.cells_dwords >> 1) << 3), 0x00020000);
-  const MatSource ms = material_source(P);
+  // (kColdArgs) the material tables' descriptors — 16 SGPRs — are built where they are used, from scalar loads of the kernel-argument segment
+  // through a pointer the compiler cannot hoist out of the loop, instead of living in SGPRs (or, spilled, in VGPR lanes: one v_readlane per
+  // dword in every event pass) across the traversal loop.  Brick builds: 17 / 18 spilled SGPRs -> 6 / 7, 4K/256^3 -0.4 %, 512^3 -0.6 %; the
+  // whole-depth build has no spills to lose and pays 1.4 % for the exposed scalar-load latency: it keeps the descriptors in registers
+  typedef const __attribute__((address_space(4))) TraceParams *KArg;
+  const KArg Pk = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+  MatSource ms_regs;
+  if (!kColdArgs) ms_regs = material_source(P);
 #ifdef TDT_STATS
   __shared__ uint32_t s_stats[(TDT_BLOCK / 64) * STAT_COUNT];
   uint32_t *const s_stat_row = &s_stats[(threadIdx.x >> 6) * STAT_COUNT];
@@ -381,6 +389,12 @@ __global__ __launch_bounds__(TDT_BLOCK) void trace_kernel(const TraceParams P) {
     if (COUNT) lane_E += (state > ST_TRAVERSE) ? 1u : 0u;
     if (state == ST_HIT) {                            // RayColor loop body rc:272-295
       if (COUNT) { cnt.scatter_slots += slot64(); cnt.scatter_active++; }
+      MatSource ms;
+      if (kColdArgs) {
+        KArg pk = Pk; asm volatile("" : "+s"(pk));
+        ms.materials = table_rsrc(pk->materials, pk->materials_dwords); ms.albedos = table_rsrc(pk->albedos, pk->albedos_dwords);
+        ms.metal = table_rsrc(pk->metal, pk->metal_dwords); ms.dielectric = table_rsrc(pk->dielectric, pk->dielectric_dwords);
+      } else ms = ms_regs;
       const MatRef mat = material_fetch(ms, hit_index);
       TDT_ST(STAT_LAMB_PASS, __ballot(mat.type == 0u)); TDT_ST(STAT_METAL_PASS, __ballot(mat.type == 1u)); TDT_ST(STAT_DIEL_PASS, __ballot(mat.type == 2u));
       if (owed.new_record()) { cube_hit_record(r, t_stride, leaf_box_x, leaf_box_y, leaf_box_z, inv_pow_depth, pc.leaf); if (COUNT) cnt.leaf_records++; }
